@@ -1,0 +1,208 @@
+/*
+ * ppn.h -- C ABI of the MI355X-native pypownet load-flow step engine (libppn.so).
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its load-flow "backend" is the
+ * Python call  pypower.api.runpf(mpc, ppopt, '', '') / rundcpf(...)  selected by the `loadflow_backend`
+ * string (reference pypownet/grid.py:48-66, 212-242) and the game rules around it live in
+ * pypownet/game.py.  This header is what a third `loadflow_backend` value ("hip") binds through ctypes;
+ * each entry point names the reference interface it replaces.  Plain pointers and sizes only; no Python
+ * or torch types cross this boundary; no exceptions: every call returns 0 or a negative PPN_E_* code and
+ * ppn_last_error() gives the text.
+ *
+ * Ownership / threading: the engine owns all device memory; the caller owns every host buffer; one engine
+ * per GPU; calls are NOT thread-safe and are stream-ordered on the engine's HIP stream
+ * (ppn_read(..., to_host=1) and ppn_sync() synchronise).
+ *
+ * Index conventions: a grid has nS substations, each with two busbars ("nodes" 0/1).  Bus ROW r of the
+ * reference's doubled bus table is (substation r % nS, node r / nS), i.e. row i+nS is the '666'-twin of
+ * row i (reference pypownet/__init__.py:10).  Elements (productions, loads, line origins/extremities) are
+ * attached to (substation, node).
+ */
+#ifndef PPN_H
+#define PPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ppn_engine ppn_engine;
+
+/* error codes */
+enum {
+  PPN_OK = 0,
+  PPN_E_INVALID = -1,   /* bad argument */
+  PPN_E_HIP = -2,       /* HIP runtime error (text in ppn_last_error) */
+  PPN_E_NODEVICE = -3,  /* no usable GPU */
+  PPN_E_CAPACITY = -4,  /* case does not fit the LDS capacities requested */
+  PPN_E_STATE = -5      /* call not valid in the current state (e.g. no chronic loaded) */
+};
+
+/* per-environment game flag (ppn_field PPN_F_FLAG): mirrors the 4th element of RunEnv.step()'s tuple
+ * (reference pypownet/game.py:856-883, environment.py:893-907). */
+enum {
+  PPN_FLAG_OK = 0,
+  PPN_FLAG_DIVERGED = 1,          /* DivergingLoadflowException */
+  PPN_FLAG_TOO_MANY_LOADS = 2,    /* TooManyConsumptionsCut (tested first, game.py:868) */
+  PPN_FLAG_TOO_MANY_PRODS = 3,    /* TooManyProductionsCut */
+  PPN_FLAG_ENGINE_CAPACITY = 4    /* engine error: active buses / LU fill exceed the configured capacity */
+};
+/* illegal-action bits (PPN_F_ILLEGAL): IllegalActionException contents, game.py:650-753 */
+enum {
+  PPN_ILL_TOO_MANY = 1, PPN_ILL_BROKEN_LINE = 2, PPN_ILL_LINE_COOLDOWN = 4, PPN_ILL_NODE_COOLDOWN = 8
+};
+
+enum { PPN_MODE_AC = 0, PPN_MODE_DC = 1 };
+enum { PPN_SOLVER_NEWTON = 1, PPN_SOLVER_FDXB = 2 };     /* = PYPOWER PF_ALG values (grid.py:63) */
+enum { PPN_LOOP_NATURAL = 0, PPN_LOOP_FIXED = 1 };       /* chronic looping (chronic.py:286-291) */
+
+/* The case: MATPOWER-v2 arrays exactly as `loadcase` returns them (reference grid.py:65), float64 row-major.
+ * bus: [2*nS x bus_cols>=13], gen: [nP x gen_cols>=8], branch: [nl x branch_cols>=11]. */
+typedef struct ppn_case {
+  int32_t n_bus_rows, bus_cols;
+  int32_t n_gen, gen_cols;
+  int32_t n_branch, branch_cols;
+  double base_mva;
+  const double* bus;
+  const double* gen;
+  const double* branch;
+} ppn_case;
+
+/* The 17 scalars of configuration.yaml (reference pypownet/parameters.py:89-153) + solver knobs. */
+typedef struct ppn_rules {
+  int32_t mode;                       /* loadflow_mode: PPN_MODE_AC | PPN_MODE_DC */
+  int32_t solver;                     /* PPN_SOLVER_NEWTON | PPN_SOLVER_FDXB */
+  double tol;                         /* PF_TOL (reference: 1e-6) */
+  int32_t max_it;                     /* PF_MAX_IT (10) / PF_MAX_IT_FD (25) */
+  double hard_overflow_coefficient;
+  int32_t n_timesteps_hard_overflow_is_broken;
+  double n_timesteps_consecutive_soft_overflow_breaks;   /* double: 1e12 when overflow cut-off is disabled */
+  int32_t n_timesteps_soft_overflow_is_broken;
+  int32_t n_timesteps_horizon_maintenance;
+  int32_t max_number_prods_game_over;
+  int32_t max_number_loads_game_over;
+  int32_t n_timesteps_actionned_line_reactionable;
+  int32_t n_timesteps_actionned_node_reactionable;
+  int32_t max_number_actionned_substations;
+  int32_t max_number_actionned_lines;
+  int32_t max_number_actionned_total;
+  int32_t game_over_mode_hard;        /* RunEnv(game_over_mode='hard'): next chronic after a game over */
+  int32_t chronic_looping;            /* PPN_LOOP_* */
+  /* engine capacities (0 = safe default: every busbar may be active) */
+  int32_t max_active_buses;
+  int32_t lu_capacity;                /* doubles of LU storage per environment, 0 = auto */
+} ppn_rules;
+
+/* One chronic as parsed by the reference reader (pypownet/chronic.py:173-229): float32 [T x n] row-major,
+ * planned series already shifted by one row, T = zip-truncated length.  ids: int32[T].  dates: int32[T x 6]
+ * (year, month, day, hour, minute, second). */
+typedef struct ppn_chronic {
+  int32_t T;
+  const float* prods_p;          /* [T x nP] */
+  const float* prods_v;          /* [T x nP], kV, <=0 => production off */
+  const float* loads_p;          /* [T x nL] */
+  const float* loads_q;
+  const float* prods_p_planned;
+  const float* prods_v_planned;
+  const float* loads_p_planned;
+  const float* loads_q_planned;
+  const float* maintenance;      /* [T x nl] */
+  const float* hazards;          /* [T x nl] */
+  const int32_t* ids;            /* [T] */
+  const int32_t* dates;          /* [T x 6] */
+} ppn_chronic;
+
+/* Fields readable (and, where noted W, writable) per environment; shapes are [batch x n]. */
+typedef enum ppn_field {
+  PPN_F_VM = 0,            /* f64 [2nS]  bus voltage magnitude p.u. per bus row            (W) */
+  PPN_F_VA,                /* f64 [2nS]  bus voltage angle, DEGREES (MATPOWER convention)  (W) */
+  PPN_F_PG,                /* f64 [nP]   gen[:,PG]                                         (W) */
+  PPN_F_QG,                /* f64 [nP]   gen[:,QG]                                         (W) */
+  PPN_F_VG,                /* f64 [nP]   gen[:,VG] (0 => production off)                   (W) */
+  PPN_F_PD,                /* f64 [nL]   load active power                                 (W) */
+  PPN_F_QD,                /* f64 [nL]                                                     (W) */
+  PPN_F_PF, PPN_F_QF, PPN_F_PT, PPN_F_QT,   /* f64 [nl] branch[:,13:17]                        */
+  PPN_F_AMPS,              /* f64 [nl]   extract_flows_a (grid.py:112-138)                     */
+  PPN_F_PRODS_NODES,       /* u8 [nP]                                                      (W) */
+  PPN_F_LOADS_NODES,       /* u8 [nL]                                                      (W) */
+  PPN_F_LINES_OR_NODES,    /* u8 [nl]                                                      (W) */
+  PPN_F_LINES_EX_NODES,    /* u8 [nl]                                                      (W) */
+  PPN_F_LINES_STATUS,      /* u8 [nl]                                                      (W) */
+  PPN_F_RECONNECTABLE,     /* i32 [nl]  timesteps_before_lines_reconnectable               (W) */
+  PPN_F_LINE_COOLDOWN,     /* i32 [nl]  timesteps_before_lines_reactionable                (W) */
+  PPN_F_NODE_COOLDOWN,     /* i32 [nS]  timesteps_before_nodes_reactionable                (W) */
+  PPN_F_SOFT_COUNT,        /* i32 [nl]  n_timesteps_soft_overflowed_lines                  (W) */
+  PPN_F_DONE,              /* u8 [1]                                                           */
+  PPN_F_FLAG,              /* i32 [1]   PPN_FLAG_*                                             */
+  PPN_F_ILLEGAL,           /* i32 [1]   PPN_ILL_* bits of the last step                        */
+  PPN_F_CASCADE_DEPTH,     /* i32 [1]   depth reached by the last cascade                      */
+  PPN_F_N_SOLVES,          /* i32 [1]   cumulative number of load-flow solves                  */
+  PPN_F_N_ITERS,           /* i32 [1]   cumulative solver iterations (NR its / FD half-its)     */
+  PPN_F_CHRONIC_SLOT,      /* i32 [1]                                                          */
+  PPN_F_CHRONIC_ROW,       /* i32 [1]   row index of the current timestep in its chronic       */
+  PPN_F_N_LOADS_CUT,       /* i32 [1]                                                          */
+  PPN_F_N_PRODS_CUT,       /* i32 [1]                                                          */
+  PPN_F_SUCCESS,           /* u8 [1]    success flag of the last solve                         */
+  PPN_F_OBSERVATION,       /* f64 [obs_len] Observation.as_array() (environment.py:583-595)    */
+  PPN_F_BUS_TYPE,          /* u8 [2nS]  bus type of the last solve: 1 PQ, 2 PV, 3 REF, 4 isolated */
+  PPN_F_COUNT
+} ppn_field;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+/* Replaces Grid.__init__ + Game.__init__ parameter plumbing (grid.py:40-95, game.py:255-340). */
+int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, int32_t device, ppn_engine** out);
+int ppn_destroy(ppn_engine* e);
+const char* ppn_last_error(const ppn_engine* e);     /* e may be NULL: error of the last failed ppn_create */
+
+/* ---- data ---------------------------------------------------------------------------------------- */
+/* Thermal limits in A (reference: Chronic.get_imaps() of the FIRST chronic, game.py:301-304). */
+int ppn_set_thermal_limits(ppn_engine* e, const double* limits /* [nl] */);
+/* Upload chronic `slot` (0..n_slots-1; slots must be loaded in order). Replaces Chronic.__init__. */
+int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c);
+
+/* ---- game ---------------------------------------------------------------------------------------- */
+/* Game.__init__ tail for the listed environments (env_ids NULL = all): initial topology, case voltages,
+ * chronic slot / first timestep row t0 (t0[i] = row loaded first; reference always 0), then one cascade
+ * solve (game.py:339-340). */
+int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* chronic_slot, const int32_t* t0);
+/* Game.step for every environment that is not done (game.py:799-885).  actions: u8 [batch x action_len],
+ * host pointer (actions_on_device=0) or device pointer (1).  simulate!=0: Game.simulate (game.py:887-943):
+ * the step runs on a scratch copy of the state and results are read with ppn_read(..., from_simulation=1).
+ * auto_reset!=0: environments that end the step done are passed through process_game_over (game.py:762-780)
+ * in the same call; PPN_F_DONE/FLAG still report the step's outcome. */
+int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
+             int32_t auto_reset);
+/* Game.process_game_over for every environment whose done flag is set (game.py:762-797).  env_mask (host,
+ * u8[batch], may be NULL) additionally forces the listed LIVE environments through it, as a caller of
+ * RunEnv.process_game_over() may do at any time (reference tests/common_assets.py:51). */
+int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask);
+/* Game.is_action_valid (game.py:755-760): valid[b] = 1/0. */
+int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_t* valid);
+
+/* ---- pure solve boundary --------------------------------------------------------------------------- */
+/* Replaces runpf(mpc, ppopt, '', '') / rundcpf (grid.py:227-229) for the whole batch on the CURRENT state
+ * (bus types are re-derived as Grid._synchronize_bus_types does).  Results: PPN_F_VM/VA/PG/QG/PF../SUCCESS. */
+int ppn_runpf_batch(ppn_engine* e);
+
+/* ---- state access ---------------------------------------------------------------------------------- */
+size_t ppn_field_bytes(const ppn_engine* e, ppn_field f);      /* bytes of one environment's field */
+int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation);
+int ppn_write(ppn_engine* e, ppn_field f, const void* src, size_t bytes);   /* whole batch, host pointer */
+int ppn_sync(ppn_engine* e);
+/* HIP stream the engine launches on (void* = hipStream_t), for callers that time with HIP events. */
+void* ppn_stream(ppn_engine* e);
+/* Average / last device time of the dominant kernel measured with HIP events on the engine stream. */
+int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, int64_t* launches);
+
+/* ---- introspection --------------------------------------------------------------------------------- */
+int32_t ppn_dim(const ppn_engine* e, int32_t which);   /* 0 nS, 1 nP, 2 nL, 3 nl, 4 action_len, 5 obs_len,
+                                                          6 batch, 7 lds_bytes, 8 max_active_buses,
+                                                          9 lu_capacity, 10 n_chronic_slots, 11 base LU fill */
+const char* ppn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPN_H */

@@ -186,7 +186,15 @@ def _newtonpf(Ybus, Sbus, V0, ref, pv, pq, tol, max_it, info):
         J21 = dS_dVa[pq][:, pvpq].imag
         J22 = dS_dVm[pq][:, pq].imag
         J = vstack([hstack([J11, J12]), hstack([J21, J22])], format='csc')
-        dx = -1 * spsolve(J, F)
+        with warnings.catch_warnings():
+            # NR is not the algorithm the reference configures (grid.py:63 uses PF_ALG=2); a singular Jacobian
+            # (islanded grid) is mapped onto the same outcome as SuperLU's "Factor is exactly singular"
+            # RuntimeError of the fast-decoupled path, i.e. pypownet's "grid is not connexe" (grid.py:230).
+            warnings.simplefilter('error', MatrixRankWarning)
+            try:
+                dx = -1 * spsolve(J, F)
+            except MatrixRankWarning:
+                raise RuntimeError('Jacobian is exactly singular')
         if npv:
             Va[pv] = Va[pv] + dx[j1:j2]
         if npq:

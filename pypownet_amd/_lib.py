@@ -1,0 +1,106 @@
+"""ctypes binding of libppn.so (include/ppn.h).  The HIP library is mandatory: there is NO CPU fallback --
+importing the engine without the built extension raises, loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libppn.so')
+
+
+class PpnCase(C.Structure):
+    _fields_ = [('n_bus_rows', C.c_int32), ('bus_cols', C.c_int32), ('n_gen', C.c_int32), ('gen_cols', C.c_int32),
+                ('n_branch', C.c_int32), ('branch_cols', C.c_int32), ('base_mva', C.c_double),
+                ('bus', C.POINTER(C.c_double)), ('gen', C.POINTER(C.c_double)), ('branch', C.POINTER(C.c_double))]
+
+
+class PpnRules(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('solver', C.c_int32), ('tol', C.c_double), ('max_it', C.c_int32),
+                ('hard_overflow_coefficient', C.c_double),
+                ('n_timesteps_hard_overflow_is_broken', C.c_int32),
+                ('n_timesteps_consecutive_soft_overflow_breaks', C.c_double),
+                ('n_timesteps_soft_overflow_is_broken', C.c_int32),
+                ('n_timesteps_horizon_maintenance', C.c_int32),
+                ('max_number_prods_game_over', C.c_int32), ('max_number_loads_game_over', C.c_int32),
+                ('n_timesteps_actionned_line_reactionable', C.c_int32),
+                ('n_timesteps_actionned_node_reactionable', C.c_int32),
+                ('max_number_actionned_substations', C.c_int32), ('max_number_actionned_lines', C.c_int32),
+                ('max_number_actionned_total', C.c_int32), ('game_over_mode_hard', C.c_int32),
+                ('chronic_looping', C.c_int32), ('max_active_buses', C.c_int32), ('lu_capacity', C.c_int32)]
+
+
+class PpnChronic(C.Structure):
+    _fields_ = [('T', C.c_int32)] + [(k, C.POINTER(C.c_float)) for k in (
+        'prods_p', 'prods_v', 'loads_p', 'loads_q', 'prods_p_planned', 'prods_v_planned', 'loads_p_planned',
+        'loads_q_planned', 'maintenance', 'hazards')] + [('ids', C.POINTER(C.c_int32)),
+                                                          ('dates', C.POINTER(C.c_int32))]
+
+
+# ppn_field enum (include/ppn.h)
+FIELDS = ['VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'PRODS_NODES', 'LOADS_NODES',
+          'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN',
+          'SOFT_COUNT', 'DONE', 'FLAG', 'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT',
+          'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE']
+FIELD_ID = {k: i for i, k in enumerate(FIELDS)}
+_F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION'}
+_U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE'}
+
+
+def field_dtype(name):
+    import numpy as np
+    if name in _F64:
+        return np.float64
+    if name in _U8:
+        return np.uint8
+    return np.int32
+
+
+EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limits', 'ppn_load_chronic', 'ppn_reset',
+           'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
+           'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version']
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            'pypownet_amd: the HIP extension %s is missing. Build it with `python __graft_entry__.py` '
+            '(hipcc --offload-arch=gfx950); this engine has no CPU fallback.' % path)
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.ppn_create.argtypes = [C.POINTER(PpnCase), C.POINTER(PpnRules), C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.ppn_create.restype = C.c_int
+    lib.ppn_destroy.argtypes = [vp]
+    lib.ppn_destroy.restype = C.c_int
+    lib.ppn_last_error.argtypes = [vp]
+    lib.ppn_last_error.restype = C.c_char_p
+    lib.ppn_set_thermal_limits.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.ppn_set_thermal_limits.restype = C.c_int
+    lib.ppn_load_chronic.argtypes = [vp, C.c_int32, C.POINTER(PpnChronic)]
+    lib.ppn_load_chronic.restype = C.c_int
+    lib.ppn_reset.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.ppn_reset.restype = C.c_int
+    lib.ppn_step.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.ppn_step.restype = C.c_int
+    lib.ppn_process_game_over.argtypes = [vp, vp]
+    lib.ppn_process_game_over.restype = C.c_int
+    lib.ppn_is_action_valid.argtypes = [vp, vp, vp]
+    lib.ppn_is_action_valid.restype = C.c_int
+    lib.ppn_runpf_batch.argtypes = [vp]
+    lib.ppn_runpf_batch.restype = C.c_int
+    lib.ppn_field_bytes.argtypes = [vp, C.c_int]
+    lib.ppn_field_bytes.restype = C.c_size_t
+    lib.ppn_read.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int32, C.c_int32]
+    lib.ppn_read.restype = C.c_int
+    lib.ppn_write.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.ppn_write.restype = C.c_int
+    lib.ppn_sync.argtypes = [vp]
+    lib.ppn_sync.restype = C.c_int
+    lib.ppn_stream.argtypes = [vp]
+    lib.ppn_stream.restype = vp
+    lib.ppn_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.ppn_kernel_time.restype = C.c_int
+    lib.ppn_dim.argtypes = [vp, C.c_int32]
+    lib.ppn_dim.restype = C.c_int32
+    lib.ppn_version.argtypes = []
+    lib.ppn_version.restype = C.c_char_p
+    return lib

@@ -1,0 +1,133 @@
+// ppn_device.h -- device-side data model of the load-flow step engine.
+//
+// One WAVEFRONT (64 lanes, one 64-thread workgroup) owns one environment.  All per-solve working data
+// (admittance matrix, Jacobian/LU, voltages, adjacency bitsets) live in that workgroup's LDS; HBM holds
+// only the compulsory per-step state (SURVEY.md 8d "B_io") laid out env-major, one contiguous row per
+// environment and field.
+//
+// The kernels are written in "phase style": LANE_LOOP { ... } regions (straight-line per-lane code on the
+// GPU) separated by WSYNC(), with wave-uniform control flow in between.  The same source also compiles
+// lane-serially with a host compiler when PPN_EMU is defined -- that build exists ONLY so that the kernel
+// logic can be unit-tested in a container without a GPU (tests/test_emu_*.py); the Python package never
+// loads it and there is no CPU fallback in the product path.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+typedef unsigned long long u64;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+#ifdef PPN_EMU
+#define PPN_DEV static inline
+#define LANE_LOOP for (int lane = 0; lane < 64; ++lane)
+#define WSYNC() ((void)0)
+#define PPN_UNI(x) (x)
+static inline int ppn_popc(u64 x) { return __builtin_popcountll(x); }
+static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
+#else
+#define PPN_DEV __device__ __forceinline__
+#define LANE_LOOP for (int lane = lane0, once_ = 1; once_; once_ = 0)
+#define WSYNC() __syncthreads()
+#define PPN_UNI(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ int ppn_popc(u64 x) { return __popcll(x); }
+__device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
+#endif
+
+#define PPN_NONE 0xFFFFu
+#define PPN_PI 3.14159265358979323846
+
+// solve outcomes (internal)
+enum { SOLVE_OK = 0, SOLVE_DIVERGED = 1, SOLVE_NOT_CONNECTED = 2, SOLVE_CAPACITY = 4 };
+
+struct DevRules {
+  int mode, solver, max_it;
+  double tol;
+  double hard_coef, n_soft_consecutive;
+  int n_hard_broken, n_soft_broken, horizon;
+  int max_prods_cut, max_loads_cut;
+  int n_line_cooldown, n_node_cooldown;
+  int max_subs, max_lines, max_total;
+  int hard_mode;
+};
+
+// Static (shared by all environments) + chronic tensors.  All pointers are device pointers.
+struct DevCase {
+  int nS, nP, nL, nl, nrows, ntopo, alen, obslen;
+  int NB, YCAP, LUCAP;     // LDS capacities: active buses, Ybus entries, LU doubles
+  double baseMVA;
+  const double *bus_gs, *bus_bs, *bus_kv, *vm0, *va0;   // [nrows]  (va0 degrees)
+  const int *gen_sub, *load_sub, *or_sub, *ex_sub;       // substation index of each element
+  const int *sub_load;                                   // [nS] load index at substation or -1
+  const double *gen_qmax, *gen_qmin, *gen_qg0;           // [nP]  (qg0: case value of gen[:,QG])
+  const double *ly;      // [nl*8]  yff.re, yff.im, yft.re, yft.im, ytf.re, ytf.im, ytt.re, ytt.im  (status on)
+  const double *lb;      // [nl*10] B' (ff,ft,tf,tt), B'' (ff,ft,tf,tt), bdc, pfinj
+  const int *pos_row;    // [nrows] bus row at elimination position p (static min-degree order, twins adjacent)
+  const int *sub_le_ptr; // [nS+1]  CSR of line ends per substation
+  const int *sub_le;     //         (line << 1) | end   (end 0 = origin, 1 = extremity)
+  const int *elem_sub;   // [ntopo] substation of each element of [prods | loads | lines_or | lines_ex]
+  const u8 *status0;     // [nl] initial line status
+  const double *limits;  // [nl] thermal limits (A)
+  const int *sub_ids;    // [nS] external substation ids (observation)
+  int slack_row;
+  // chronics: slot s occupies rows [c_off[s], c_off[s]+c_T[s]) of every tensor
+  int n_slots;
+  const float *c_pp, *c_pv, *c_lp, *c_lq, *c_ppp, *c_pvp, *c_lpp, *c_lqp, *c_mt, *c_hz;
+  const int *c_off, *c_T, *c_next, *c_roll, *c_restart;
+  const int *c_dates;    // [rows x 6]
+  DevRules R;
+};
+
+// Mutable per-environment state, env-major: field[env * n + k].
+struct DevState {
+  double *vm, *va;                 // [nrows]  (va degrees)
+  double *pg, *qg, *vg;            // [nP]
+  double *pd, *qd;                 // [nL]
+  double *pf, *qf, *pt, *qt, *amps;  // [nl]
+  u8 *pn, *ln, *on, *en, *st;      // node bits / line status
+  int *rec, *lcd, *ncd, *soft;     // counters
+  u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
+  int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
+};
+
+// LDS carve-up (pointers into the workgroup's dynamic shared memory)
+struct Smem {
+  u64 *adj0, *adjF;
+  double *yre, *yim, *lu;
+  double *vm, *va, *vr, *vi, *psp, *qsp, *mr, *mi, *rhs, *gvg, *pinj;
+  double *amps;
+  u16 *yptr, *luoff, *luoff2, *row2int, *int2row, *slist, *scn;
+  u8 *nv, *nv2, *touched, *hasgen, *genon;
+  u8 *st, *on, *en, *pn, *ln, *subchg, *act, *over;
+  int *red;
+};
+
+#ifdef PPN_EMU
+#define PPN_HD static inline
+#else
+#define PPN_HD __host__ __device__ __forceinline__
+#endif
+
+// Single definition of the LDS layout: carves `base` into S and returns the total size in bytes
+// (call with base == nullptr on the host to size the launch).
+PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) {
+  Smem& S = *Sp;
+  size_t o = 0;
+  const size_t NB = d.NB, nl = d.nl, nrows = d.nrows;
+#define PPN_TAKE(field, type, bytes) S.field = (type*)(base + o); o += (((size_t)(bytes)) + 15) & ~(size_t)15;
+  PPN_TAKE(adj0, u64, NB * W * 8) PPN_TAKE(adjF, u64, NB * W * 8)
+  PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8)
+  PPN_TAKE(lu, double, (size_t)d.LUCAP * 8)
+  PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(vr, double, NB * 8) PPN_TAKE(vi, double, NB * 8)
+  PPN_TAKE(psp, double, NB * 8) PPN_TAKE(qsp, double, NB * 8) PPN_TAKE(mr, double, NB * 8) PPN_TAKE(mi, double, NB * 8)
+  PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(pinj, double, NB * 8)
+  PPN_TAKE(amps, double, nl * 8)
+  PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(luoff, u16, (NB + 1) * 2) PPN_TAKE(luoff2, u16, (NB + 1) * 2)
+  PPN_TAKE(row2int, u16, nrows * 2) PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(slist, u16, 64 * 2)
+  PPN_TAKE(scn, u16, (nrows + 1) * 2)
+  PPN_TAKE(nv, u8, NB) PPN_TAKE(nv2, u8, NB) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
+  PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
+  PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen) PPN_TAKE(over, u8, nl) PPN_TAKE(red, int, 64 * 4)
+#undef PPN_TAKE
+  return o;
+}

@@ -1,0 +1,778 @@
+// ppn_engine.hip -- host side of libppn.so: the C ABI of include/ppn.h, device memory management, kernel launches.
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ppn_engine.hip -o libppn.so
+// (tests only: g++ -DPPN_EMU -x c++ ... -> lane-serial host build of the same kernels, see ppn_device.h)
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <math.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#ifndef PPN_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+#include "../../include/ppn.h"
+#include "ppn_device.h"
+#include "ppn_solve.inc"
+#include "ppn_game.inc"
+#include "ppn_obs.inc"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// device memory abstraction (HIP, or plain host memory in the test-only emulation build)
+#ifdef PPN_EMU
+typedef int hipStream_t;
+static int dev_malloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? 0 : -1; }
+static void dev_free(void* p) { free(p); }
+static int dev_h2d(void* d, const void* h, size_t n, hipStream_t) { memcpy(d, h, n); return 0; }
+static int dev_d2h(void* h, const void* d, size_t n, hipStream_t) { memcpy(h, d, n); return 0; }
+static int dev_d2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+static int dev_zero(void* d, size_t n, hipStream_t) { memset(d, 0, n); return 0; }
+static const char* dev_err() { return "emulation"; }
+#else
+static int dev_malloc(void** p, size_t n) { return hipMalloc(p, n ? n : 1) == hipSuccess ? 0 : -1; }
+static void dev_free(void* p) { if (p) (void)hipFree(p); }
+static int dev_h2d(void* d, const void* h, size_t n, hipStream_t s) {
+  if (hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;   // host buffers are pageable and caller-owned
+}
+static int dev_d2h(void* h, const void* d, size_t n, hipStream_t s) {
+  if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+static int dev_d2d(void* d, const void* s_, size_t n, hipStream_t s) {
+  return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
+}
+static int dev_zero(void* d, size_t n, hipStream_t s) { return hipMemsetAsync(d, 0, n, s) == hipSuccess ? 0 : -1; }
+static const char* dev_err() { return hipGetErrorString(hipGetLastError()); }
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct HostChronic {
+  int T;
+  std::vector<float> pp, pv, lp, lq, ppp, pvp, lpp, lqp, mt, hz;
+  std::vector<int> ids, dates;
+};
+
+struct FieldDesc { void** base; size_t elem; int n; };
+
+struct ppn_engine {
+  int batch = 0, device = 0, W = 1;
+  DevCase dc;
+  DevState st, sim;
+  std::vector<void*> allocs;
+  std::vector<HostChronic> chronics;
+  bool chronics_dirty = true;
+  std::vector<void*> chronic_allocs;
+  hipStream_t stream = 0;
+  size_t lds_bytes = 0;
+  int base_fill = 0;
+  std::string err;
+  u8* d_actions = nullptr;
+  double* d_obs = nullptr;
+  u8* d_valid = nullptr;
+  int* d_ids = nullptr;     // scratch for ppn_reset: env ids, slots, t0 (3 * batch)
+  ppn_rules rules;
+  // kernel timing
+#ifndef PPN_EMU
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+#endif
+  double time_ms = 0.0;
+  long long launches = 0;
+};
+
+static std::string g_create_error;
+
+static int fail(ppn_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_error = buf;
+  return code;
+}
+
+template <typename T>
+static T* upload(ppn_engine* e, const std::vector<T>& v, std::vector<void*>& pool) {
+  void* p = nullptr;
+  if (dev_malloc(&p, v.size() * sizeof(T) + 16)) return nullptr;
+  pool.push_back(p);
+  if (!v.empty()) dev_h2d(p, v.data(), v.size() * sizeof(T), e->stream);
+  return (T*)p;
+}
+
+template <typename T>
+static T* dalloc(ppn_engine* e, size_t n) {
+  void* p = nullptr;
+  if (dev_malloc(&p, n * sizeof(T) + 16)) return nullptr;
+  e->allocs.push_back(p);
+  dev_zero(p, n * sizeof(T), e->stream);
+  return (T*)p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels / launchers
+enum { K_STEP = 0, K_GAMEOVER, K_RESET, K_RUNPF, K_VALID, K_OBS };
+
+struct KArgs {
+  DevCase d;
+  DevState st;
+  const u8* actions;
+  u8* valid;
+  const int *ids, *slots, *t0;
+  double* obs;
+  int sim;
+};
+
+#ifndef PPN_EMU
+template <int W, int KIND>
+__global__ void __launch_bounds__(64) ppn_kernel(const KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Smem S;
+  ppn_carve(a.d, W, smem, &S);
+  const int env = blockIdx.x;
+  const int lane0 = threadIdx.x;
+  if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, env, lane0);
+  else if (KIND == K_GAMEOVER) body_game_over<W>(a.d, a.st, S, a.valid, env, lane0);
+  else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, lane0);
+  else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, lane0);
+  else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, lane0);
+  else if (KIND == K_OBS) body_obs(a.d, a.st, S, a.obs, env, lane0);
+}
+#endif
+
+template <int W, int KIND>
+static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
+#ifdef PPN_EMU
+  (void)timed;
+  std::vector<unsigned char> lds(e->lds_bytes + 64);
+  unsigned char* base = (unsigned char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+  Smem S;
+  ppn_carve(a.d, W, base, &S);
+  for (int env = 0; env < nblocks; ++env) {
+    memset(base, 0xA5, e->lds_bytes);   // LDS is NOT zero-initialised on the GPU either
+    if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, env, 0);
+    else if (KIND == K_GAMEOVER) body_game_over<W>(a.d, a.st, S, a.valid, env, 0);
+    else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
+    else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, 0);
+    else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, 0);
+    else if (KIND == K_OBS) body_obs(a.d, a.st, S, a.obs, env, 0);
+  }
+  if (timed) e->launches++;
+  return 0;
+#else
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    if (e->ev_used + 2 > e->ev.size()) {
+      for (int k = 0; k < 512; ++k) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return -1; e->ev.push_back(ev); }
+    }
+    e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
+    (void)hipEventRecord(e0, e->stream);
+  }
+  hipLaunchKernelGGL((ppn_kernel<W, KIND>), dim3(nblocks), dim3(64), e->lds_bytes, e->stream, a);
+  if (timed) { (void)hipEventRecord(e1, e->stream); e->launches++; }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+#endif
+}
+
+template <int KIND>
+static int launch(ppn_engine* e, const KArgs& a, int nblocks, bool timed = false) {
+  switch (e->W) {
+    case 1: return launch_w<1, KIND>(e, a, nblocks, timed);
+    case 2: return launch_w<2, KIND>(e, a, nblocks, timed);
+    case 3: return launch_w<3, KIND>(e, a, nblocks, timed);
+    default: return launch_w<4, KIND>(e, a, nblocks, timed);
+  }
+}
+
+#ifndef PPN_EMU
+template <int W>
+static int set_lds_attr(size_t bytes) {
+  int rc = 0;
+  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_GAMEOVER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_RESET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_RUNPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_VALID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+  return rc;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-side analysis: static elimination order (minimum degree on the substation graph) and its fill
+static void min_degree_order(int nS, const std::vector<int>& f, const std::vector<int>& t, std::vector<int>& order) {
+  std::vector<std::vector<char>> adj(nS, std::vector<char>(nS, 0));
+  for (size_t k = 0; k < f.size(); ++k) if (f[k] != t[k]) { adj[f[k]][t[k]] = 1; adj[t[k]][f[k]] = 1; }
+  std::vector<char> gone(nS, 0);
+  order.clear();
+  for (int step = 0; step < nS; ++step) {
+    int best = -1, bestdeg = 1 << 30;
+    for (int i = 0; i < nS; ++i) if (!gone[i]) {
+      int deg = 0;
+      for (int j = 0; j < nS; ++j) if (!gone[j] && adj[i][j]) ++deg;
+      if (deg < bestdeg) { bestdeg = deg; best = i; }
+    }
+    gone[best] = 1;
+    order.push_back(best);
+    std::vector<int> nb;
+    for (int j = 0; j < nS; ++j) if (!gone[j] && adj[best][j]) nb.push_back(j);
+    for (int a : nb) for (int b : nb) if (a != b) adj[a][b] = 1;
+  }
+}
+
+// number of (i,j) pairs of the filled pattern (incl. diagonal) when eliminating in `order`
+static int filled_pairs(int nS, const std::vector<int>& f, const std::vector<int>& t, const std::vector<int>& order,
+                        std::vector<std::vector<char>>* out = nullptr) {
+  std::vector<int> pos(nS);
+  for (int p = 0; p < nS; ++p) pos[order[p]] = p;
+  std::vector<std::vector<char>> a(nS, std::vector<char>(nS, 0));
+  for (int i = 0; i < nS; ++i) a[i][i] = 1;
+  for (size_t k = 0; k < f.size(); ++k) { a[pos[f[k]]][pos[t[k]]] = 1; a[pos[t[k]]][pos[f[k]]] = 1; }
+  for (int k = 0; k < nS; ++k) {
+    std::vector<int> nb;
+    for (int j = k + 1; j < nS; ++j) if (a[k][j]) nb.push_back(j);
+    for (int x : nb) for (int y : nb) a[x][y] = 1;
+  }
+  int cnt = 0;
+  for (int i = 0; i < nS; ++i) for (int j = 0; j < nS; ++j) cnt += a[i][j];
+  if (out) *out = a;
+  return cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" const char* ppn_version(void) { return "pypownet_amd libppn 0.1 (gfx950)"; }
+
+extern "C" const char* ppn_last_error(const ppn_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+static void free_all(ppn_engine* e) {
+  for (void* p : e->allocs) dev_free(p);
+  for (void* p : e->chronic_allocs) dev_free(p);
+  e->allocs.clear(); e->chronic_allocs.clear();
+#ifndef PPN_EMU
+  for (auto ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+#endif
+}
+
+extern "C" int ppn_destroy(ppn_engine* e) {
+  if (!e) return PPN_E_INVALID;
+  free_all(e);
+  delete e;
+  return PPN_OK;
+}
+
+static int alloc_state(ppn_engine* e, DevState* s) {
+  const DevCase& d = e->dc;
+  const size_t B = e->batch;
+  s->vm = dalloc<double>(e, B * d.nrows); s->va = dalloc<double>(e, B * d.nrows);
+  s->pg = dalloc<double>(e, B * d.nP); s->qg = dalloc<double>(e, B * d.nP); s->vg = dalloc<double>(e, B * d.nP);
+  s->pd = dalloc<double>(e, B * d.nL); s->qd = dalloc<double>(e, B * d.nL);
+  s->pf = dalloc<double>(e, B * d.nl); s->qf = dalloc<double>(e, B * d.nl); s->pt = dalloc<double>(e, B * d.nl);
+  s->qt = dalloc<double>(e, B * d.nl); s->amps = dalloc<double>(e, B * d.nl);
+  s->pn = dalloc<u8>(e, B * d.nP); s->ln = dalloc<u8>(e, B * d.nL); s->on = dalloc<u8>(e, B * d.nl);
+  s->en = dalloc<u8>(e, B * d.nl); s->st = dalloc<u8>(e, B * d.nl);
+  s->rec = dalloc<int>(e, B * d.nl); s->lcd = dalloc<int>(e, B * d.nl); s->ncd = dalloc<int>(e, B * d.nS);
+  s->soft = dalloc<int>(e, B * d.nl);
+  s->done = dalloc<u8>(e, B); s->dead = dalloc<u8>(e, B); s->succ = dalloc<u8>(e, B);
+  s->btype = dalloc<u8>(e, B * d.nrows);
+  s->flag = dalloc<int>(e, B); s->ill = dalloc<int>(e, B); s->depth = dalloc<int>(e, B);
+  s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
+  s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
+  return s->epoch ? 0 : -1;
+}
+
+struct FieldInfo { size_t elem; int n; size_t off; };   // off: byte offset of the pointer inside DevState
+
+static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* writable) {
+  const DevCase& d = e->dc;
+#define FI(member, type, count, w) { fi->elem = sizeof(type); fi->n = (count); fi->off = offsetof(DevState, member); *writable = (w); return true; }
+  switch (f) {
+    case PPN_F_VM: FI(vm, double, d.nrows, true)
+    case PPN_F_VA: FI(va, double, d.nrows, true)
+    case PPN_F_PG: FI(pg, double, d.nP, true)
+    case PPN_F_QG: FI(qg, double, d.nP, true)
+    case PPN_F_VG: FI(vg, double, d.nP, true)
+    case PPN_F_PD: FI(pd, double, d.nL, true)
+    case PPN_F_QD: FI(qd, double, d.nL, true)
+    case PPN_F_PF: FI(pf, double, d.nl, false)
+    case PPN_F_QF: FI(qf, double, d.nl, false)
+    case PPN_F_PT: FI(pt, double, d.nl, false)
+    case PPN_F_QT: FI(qt, double, d.nl, false)
+    case PPN_F_AMPS: FI(amps, double, d.nl, false)
+    case PPN_F_PRODS_NODES: FI(pn, u8, d.nP, true)
+    case PPN_F_LOADS_NODES: FI(ln, u8, d.nL, true)
+    case PPN_F_LINES_OR_NODES: FI(on, u8, d.nl, true)
+    case PPN_F_LINES_EX_NODES: FI(en, u8, d.nl, true)
+    case PPN_F_LINES_STATUS: FI(st, u8, d.nl, true)
+    case PPN_F_RECONNECTABLE: FI(rec, int, d.nl, true)
+    case PPN_F_LINE_COOLDOWN: FI(lcd, int, d.nl, true)
+    case PPN_F_NODE_COOLDOWN: FI(ncd, int, d.nS, true)
+    case PPN_F_SOFT_COUNT: FI(soft, int, d.nl, true)
+    case PPN_F_DONE: FI(done, u8, 1, false)
+    case PPN_F_FLAG: FI(flag, int, 1, false)
+    case PPN_F_ILLEGAL: FI(ill, int, 1, false)
+    case PPN_F_CASCADE_DEPTH: FI(depth, int, 1, false)
+    case PPN_F_N_SOLVES: FI(nsolve, int, 1, false)
+    case PPN_F_N_ITERS: FI(niter, int, 1, false)
+    case PPN_F_CHRONIC_SLOT: FI(slot, int, 1, false)
+    case PPN_F_CHRONIC_ROW: FI(row, int, 1, false)
+    case PPN_F_N_LOADS_CUT: FI(nlc, int, 1, false)
+    case PPN_F_N_PRODS_CUT: FI(npc, int, 1, false)
+    case PPN_F_SUCCESS: FI(succ, u8, 1, false)
+    case PPN_F_BUS_TYPE: FI(btype, u8, d.nrows, false)
+    default: return false;
+  }
+#undef FI
+}
+
+extern "C" size_t ppn_field_bytes(const ppn_engine* e, ppn_field f) {
+  if (!e) return 0;
+  if (f == PPN_F_OBSERVATION) return (size_t)e->dc.obslen * sizeof(double);
+  FieldInfo fi; bool w;
+  if (!field_info(e, f, &fi, &w)) return 0;
+  return fi.elem * fi.n;
+}
+
+extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
+  if (!e) return -1;
+  const DevCase& d = e->dc;
+  switch (which) {
+    case 0: return d.nS; case 1: return d.nP; case 2: return d.nL; case 3: return d.nl;
+    case 4: return d.alen; case 5: return d.obslen; case 6: return e->batch; case 7: return (int32_t)e->lds_bytes;
+    case 8: return d.NB; case 9: return d.LUCAP; case 10: return (int32_t)e->chronics.size(); case 11: return e->base_fill;
+    default: return -1;
+  }
+}
+
+extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, int32_t device, ppn_engine** out) {
+  if (!c || !r || !out || batch <= 0) return fail(nullptr, PPN_E_INVALID, "ppn_create: null argument or batch <= 0");
+  if (c->n_bus_rows <= 0 || (c->n_bus_rows & 1) || c->bus_cols < 10 || c->gen_cols < 8 || c->branch_cols < 11)
+    return fail(nullptr, PPN_E_INVALID, "ppn_create: case arrays have unexpected shapes");
+  ppn_engine* e = new ppn_engine();
+  e->batch = batch; e->device = device; e->rules = *r;
+#ifndef PPN_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete e; return fail(nullptr, PPN_E_NODEVICE, "no HIP device visible"); }
+  if (hipSetDevice(device) != hipSuccess) { delete e; return fail(nullptr, PPN_E_NODEVICE, "hipSetDevice(%d) failed", device); }
+  if (hipStreamCreate(&e->stream) != hipSuccess) { delete e; return fail(nullptr, PPN_E_HIP, "hipStreamCreate failed"); }
+#endif
+  DevCase& d = e->dc;
+  memset(&d, 0, sizeof d);
+  const int nrows = c->n_bus_rows, nS = nrows / 2, nP = c->n_gen, nl = c->n_branch;
+  const double* bus = c->bus; const double* gen = c->gen; const double* br = c->branch;
+  const int bc = c->bus_cols, gc = c->gen_cols, rc = c->branch_cols;
+  auto bad = [&](const char* m) { free_all(e); delete e; return fail(nullptr, PPN_E_INVALID, "ppn_create: %s", m); };
+
+  // bus id -> row
+  std::vector<long long> ids(nrows);
+  for (int i = 0; i < nrows; ++i) ids[i] = (long long)bus[(size_t)i * bc + 0];
+  auto row_of = [&](double id) { long long v = (long long)id; for (int i = 0; i < nrows; ++i) if (ids[i] == v) return i; return -1; };
+  for (int i = 0; i < nS; ++i) {
+    char tw[64];
+    snprintf(tw, sizeof tw, "666%lld", ids[i]);
+    if (ids[i + nS] != atoll(tw)) return bad("bus row i+nS must be the '666'-twin of row i");
+  }
+  std::vector<double> gs(nrows), bs(nrows), kv(nrows), vm0(nrows), va0(nrows);
+  std::vector<int> loads;   // rows with Pd != 0 or Qd != 0 (grid.py:77)
+  int slack_row = -1;
+  for (int i = 0; i < nrows; ++i) {
+    const double* b = bus + (size_t)i * bc;
+    gs[i] = b[4]; bs[i] = b[5]; kv[i] = b[9]; vm0[i] = b[7]; va0[i] = b[8];
+    if (b[2] != 0.0 || b[3] != 0.0) loads.push_back(i);
+    if (slack_row < 0 && (int)b[1] == 3) slack_row = i;
+  }
+  if (slack_row < 0) return bad("case has no slack bus (type 3)");
+  const int nL = (int)loads.size();
+  std::vector<int> gen_sub(nP), load_sub(nL), or_sub(nl), ex_sub(nl), sub_load(nS, -1), sub_gen(nS, -1);
+  std::vector<double> qmax(nP), qmin(nP), qg0(nP);
+  for (int g = 0; g < nP; ++g) {
+    const int r_ = row_of(gen[(size_t)g * gc + 0]);
+    if (r_ < 0 || r_ >= nS) return bad("production bus must be a real (non-twin) bus of the case");
+    gen_sub[g] = r_;
+    if (sub_gen[r_] >= 0) return bad("more than one production per substation is not supported");
+    if (g > 0 && gen_sub[g] <= gen_sub[g - 1]) return bad("productions must be sorted by substation");
+    sub_gen[r_] = g;
+    qmax[g] = gen[(size_t)g * gc + 3]; qmin[g] = gen[(size_t)g * gc + 4]; qg0[g] = gen[(size_t)g * gc + 2];
+  }
+  for (int q = 0; q < nL; ++q) {
+    if (loads[q] >= nS) return bad("loads on twin rows in the reference grid are not supported");
+    load_sub[q] = loads[q];
+    sub_load[loads[q]] = q;
+  }
+  std::vector<double> ly((size_t)nl * 8), lb((size_t)nl * 10);
+  std::vector<u8> status0(nl);
+  for (int l = 0; l < nl; ++l) {
+    const double* b = br + (size_t)l * rc;
+    const int f = row_of(b[0]), t = row_of(b[1]);
+    if (f < 0 || t < 0 || f >= nS || t >= nS) return bad("line endpoints must be real buses of the case");
+    or_sub[l] = f; ex_sub[l] = t;
+    status0[l] = (u8)(b[10] != 0.0);
+    const double rr = b[2], x = b[3], bch = b[4];
+    const double tapm = (b[8] != 0.0) ? b[8] : 1.0, sh = b[9] * M_PI / 180.0;
+    // makeYbus (status on):  Ys = 1/(r+jx); Ytt = Ys + j b/2; Yff = Ytt/(tap conj(tap)); Yft = -Ys/conj(tap); Ytf = -Ys/tap
+    auto branch_y = [&](double r_, double x_, double b_, double tm, double shift, double* o) {
+      const double den = r_ * r_ + x_ * x_;
+      const double ysr = r_ / den, ysi = -x_ / den;
+      const double tr = tm * cos(shift), ti = tm * sin(shift);
+      const double t2 = tr * tr + ti * ti;
+      const double yttr = ysr, ytti = ysi + b_ / 2.0;
+      o[0] = yttr / t2; o[1] = ytti / t2;                                 // Yff
+      // -Ys / conj(tap) = -Ys * tap / |tap|^2
+      o[2] = -(ysr * tr - ysi * ti) / t2; o[3] = -(ysr * ti + ysi * tr) / t2;   // Yft
+      // -Ys / tap = -Ys * conj(tap) / |tap|^2
+      o[4] = -(ysr * tr + ysi * ti) / t2; o[5] = -(-ysr * ti + ysi * tr) / t2;  // Ytf
+      o[6] = yttr; o[7] = ytti;                                           // Ytt
+    };
+    branch_y(rr, x, bch, tapm, sh, &ly[(size_t)l * 8]);
+    double yp[8], yq[8];
+    branch_y(0.0, x, 0.0, 1.0, sh, yp);        // B' (XB): r = 0, b = 0, tap = 1 (shift kept)
+    branch_y(rr, x, bch, tapm, 0.0, yq);       // B'': shift = 0
+    double* o = &lb[(size_t)l * 10];
+    o[0] = -yp[1]; o[1] = -yp[3]; o[2] = -yp[5]; o[3] = -yp[7];
+    o[4] = -yq[1]; o[5] = -yq[3]; o[6] = -yq[5]; o[7] = -yq[7];
+    o[8] = 1.0 / x / tapm;                     // makeBdc: b = status / x / tap
+    o[9] = -o[8] * b[9] * M_PI / 180.0;        // Pfinj = b * (-shift)
+  }
+  // elimination order and fill
+  std::vector<int> order;
+  min_degree_order(nS, or_sub, ex_sub, order);
+  std::vector<int> pos_row(nrows);
+  for (int p = 0; p < nS; ++p) { pos_row[2 * p] = order[p]; pos_row[2 * p + 1] = order[p] + nS; }
+  std::vector<std::vector<char>> filled;
+  const int pairs = filled_pairs(nS, or_sub, ex_sub, order, &filled);
+  // LU doubles of the Newton Jacobian with the case's own bus types (PV where a production sits, slack = ref)
+  {
+    std::vector<int> pos(nS), nvs(nS);
+    for (int p = 0; p < nS; ++p) pos[order[p]] = p;
+    for (int s = 0; s < nS; ++s) nvs[pos[s]] = (s == slack_row % nS) ? 0 : (sub_gen[s] >= 0 ? 1 : 2);
+    int tot = 0;
+    for (int i = 0; i < nS; ++i) for (int j = 0; j < nS; ++j) if (filled[i][j]) tot += nvs[i] * nvs[j];
+    e->base_fill = tot;
+  }
+  // sub -> line ends CSR
+  std::vector<int> le_ptr(nS + 1, 0), le;
+  for (int l = 0; l < nl; ++l) { le_ptr[or_sub[l] + 1]++; le_ptr[ex_sub[l] + 1]++; }
+  for (int s = 0; s < nS; ++s) le_ptr[s + 1] += le_ptr[s];
+  le.resize(2 * nl);
+  {
+    std::vector<int> fill(le_ptr.begin(), le_ptr.end() - 1);
+    for (int l = 0; l < nl; ++l) { le[fill[or_sub[l]]++] = (l << 1); le[fill[ex_sub[l]]++] = (l << 1) | 1; }
+  }
+  std::vector<int> elem_sub;
+  elem_sub.insert(elem_sub.end(), gen_sub.begin(), gen_sub.end());
+  elem_sub.insert(elem_sub.end(), load_sub.begin(), load_sub.end());
+  elem_sub.insert(elem_sub.end(), or_sub.begin(), or_sub.end());
+  elem_sub.insert(elem_sub.end(), ex_sub.begin(), ex_sub.end());
+  std::vector<int> sub_ids(nS);
+  for (int s = 0; s < nS; ++s) sub_ids[s] = (int)ids[s];
+
+  d.nS = nS; d.nP = nP; d.nL = nL; d.nl = nl; d.nrows = nrows; d.ntopo = nP + nL + 2 * nl; d.alen = d.ntopo + nl;
+  d.obslen = 9 * nL + 9 * nP + 18 * nl + 2 * nS + 6;
+  d.baseMVA = c->base_mva; d.slack_row = slack_row;
+  int NB = r->max_active_buses > 0 ? std::min(r->max_active_buses, nrows) : nrows;
+  if (NB < 2) NB = 2;
+  if (NB > 256) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "more than 256 active busbars are not supported"); }
+  d.NB = NB;
+  e->W = (NB + 63) / 64;
+  d.YCAP = NB + 2 * nl;
+  int lucap = r->lu_capacity;
+  if (lucap <= 0) {
+    lucap = (int)(e->base_fill * 1.30) + 192;
+    if (NB > nS) lucap = (int)(lucap * 1.6);
+    const int fd_need = 2 * pairs + 64;        // B' + B'' storages of the fast-decoupled solver
+    if (lucap < fd_need) lucap = fd_need;
+  }
+  d.LUCAP = (lucap + 7) & ~7;
+  if (d.LUCAP > 65000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds 16-bit offsets"); }
+  { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); }
+  if (e->lds_bytes > 160 * 1024) {
+    free_all(e); delete e;
+    return fail(nullptr, PPN_E_CAPACITY, "case needs %zu bytes of LDS per environment (limit 160 KiB)", e->lds_bytes);
+  }
+  d.bus_gs = upload(e, gs, e->allocs); d.bus_bs = upload(e, bs, e->allocs); d.bus_kv = upload(e, kv, e->allocs);
+  d.vm0 = upload(e, vm0, e->allocs); d.va0 = upload(e, va0, e->allocs);
+  d.gen_sub = upload(e, gen_sub, e->allocs); d.load_sub = upload(e, load_sub, e->allocs);
+  d.or_sub = upload(e, or_sub, e->allocs); d.ex_sub = upload(e, ex_sub, e->allocs);
+  d.sub_load = upload(e, sub_load, e->allocs);
+  d.gen_qmax = upload(e, qmax, e->allocs); d.gen_qmin = upload(e, qmin, e->allocs); d.gen_qg0 = upload(e, qg0, e->allocs);
+  d.ly = upload(e, ly, e->allocs); d.lb = upload(e, lb, e->allocs);
+  d.pos_row = upload(e, pos_row, e->allocs);
+  d.sub_le_ptr = upload(e, le_ptr, e->allocs); d.sub_le = upload(e, le, e->allocs);
+  d.elem_sub = upload(e, elem_sub, e->allocs);
+  d.status0 = upload(e, status0, e->allocs);
+  d.sub_ids = upload(e, sub_ids, e->allocs);
+  std::vector<double> lim(nl, 1e30);
+  d.limits = upload(e, lim, e->allocs);
+
+  DevRules& R = d.R;
+  R.mode = r->mode; R.solver = r->solver; R.max_it = r->max_it; R.tol = r->tol;
+  R.hard_coef = r->hard_overflow_coefficient; R.n_soft_consecutive = r->n_timesteps_consecutive_soft_overflow_breaks;
+  R.n_hard_broken = r->n_timesteps_hard_overflow_is_broken; R.n_soft_broken = r->n_timesteps_soft_overflow_is_broken;
+  R.horizon = r->n_timesteps_horizon_maintenance;
+  R.max_prods_cut = r->max_number_prods_game_over; R.max_loads_cut = r->max_number_loads_game_over;
+  R.n_line_cooldown = r->n_timesteps_actionned_line_reactionable;
+  R.n_node_cooldown = r->n_timesteps_actionned_node_reactionable;
+  R.max_subs = r->max_number_actionned_substations; R.max_lines = r->max_number_actionned_lines;
+  R.max_total = r->max_number_actionned_total; R.hard_mode = r->game_over_mode_hard;
+  if (R.solver != PPN_SOLVER_NEWTON && R.solver != PPN_SOLVER_FDXB) return bad("solver must be NEWTON or FDXB");
+  if (R.max_it <= 0) R.max_it = (R.solver == PPN_SOLVER_NEWTON) ? 10 : 25;
+  if (!(R.tol > 0)) R.tol = 1e-6;
+
+  if (alloc_state(e, &e->st) || alloc_state(e, &e->sim)) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
+  e->d_actions = dalloc<u8>(e, (size_t)batch * d.alen);
+  e->d_valid = dalloc<u8>(e, batch);
+  e->d_ids = dalloc<int>(e, (size_t)3 * batch);
+  e->d_obs = dalloc<double>(e, (size_t)batch * d.obslen);
+  if (!e->d_obs) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
+#ifndef PPN_EMU
+  int rc_attr = 0;
+  switch (e->W) { case 1: rc_attr = set_lds_attr<1>(e->lds_bytes); break; case 2: rc_attr = set_lds_attr<2>(e->lds_bytes); break;
+                  case 3: rc_attr = set_lds_attr<3>(e->lds_bytes); break; default: rc_attr = set_lds_attr<4>(e->lds_bytes); }
+  if (rc_attr) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, dev_err()); }
+  if (hipStreamSynchronize(e->stream) != hipSuccess) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "upload failed: %s", dev_err()); }
+#endif
+  *out = e;
+  return PPN_OK;
+}
+
+extern "C" int ppn_set_thermal_limits(ppn_engine* e, const double* limits) {
+  if (!e || !limits) return PPN_E_INVALID;
+  return dev_h2d((void*)e->dc.limits, limits, sizeof(double) * e->dc.nl, e->stream) ? fail(e, PPN_E_HIP, "limits upload failed") : PPN_OK;
+}
+
+extern "C" int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c) {
+  if (!e || !c || c->T <= 0) return PPN_E_INVALID;
+  if (slot < 0 || slot > (int)e->chronics.size()) return fail(e, PPN_E_INVALID, "chronic slots must be loaded in order");
+  const DevCase& d = e->dc;
+  HostChronic h;
+  h.T = c->T;
+  auto cp = [&](std::vector<float>& v, const float* src, int n) { v.assign(src, src + (size_t)c->T * n); };
+  cp(h.pp, c->prods_p, d.nP); cp(h.pv, c->prods_v, d.nP); cp(h.lp, c->loads_p, d.nL); cp(h.lq, c->loads_q, d.nL);
+  cp(h.ppp, c->prods_p_planned, d.nP); cp(h.pvp, c->prods_v_planned, d.nP);
+  cp(h.lpp, c->loads_p_planned, d.nL); cp(h.lqp, c->loads_q_planned, d.nL);
+  cp(h.mt, c->maintenance, d.nl); cp(h.hz, c->hazards, d.nl);
+  h.ids.assign(c->ids, c->ids + c->T);
+  if (c->dates) h.dates.assign(c->dates, c->dates + (size_t)c->T * 6); else h.dates.assign((size_t)c->T * 6, 0);
+  if (slot == (int)e->chronics.size()) e->chronics.push_back(std::move(h)); else e->chronics[slot] = std::move(h);
+  e->chronics_dirty = true;
+  return PPN_OK;
+}
+
+static int index_of(const std::vector<int>& v, int x) { for (size_t i = 0; i < v.size(); ++i) if (v[i] == x) return (int)i; return -1; }
+
+static int sync_chronics(ppn_engine* e) {
+  if (!e->chronics_dirty) return PPN_OK;
+  if (e->chronics.empty()) return fail(e, PPN_E_STATE, "no chronic loaded");
+#ifndef PPN_EMU
+  (void)hipStreamSynchronize(e->stream);
+#endif
+  for (void* p : e->chronic_allocs) dev_free(p);
+  e->chronic_allocs.clear();
+  const int ns = (int)e->chronics.size();
+  std::vector<int> off(ns), T(ns), next(ns), roll(ns), restart(ns), dates;
+  std::vector<float> pp, pv, lp, lq, ppp, pvp, lpp, lqp, mt, hz;
+  int rows = 0;
+  for (int s = 0; s < ns; ++s) {
+    const HostChronic& h = e->chronics[s];
+    off[s] = rows; T[s] = h.T; rows += h.T;
+    next[s] = (e->rules.chronic_looping == PPN_LOOP_FIXED) ? s : (s + 1) % ns;
+    auto app = [](std::vector<float>& dst, const std::vector<float>& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    app(pp, h.pp); app(pv, h.pv); app(lp, h.lp); app(lq, h.lq); app(ppp, h.ppp); app(pvp, h.pvp); app(lpp, h.lpp);
+    app(lqp, h.lqp); app(mt, h.mt); app(hz, h.hz);
+    dates.insert(dates.end(), h.dates.begin(), h.dates.end());
+  }
+  for (int s = 0; s < ns; ++s) {
+    // roll-over (game.py:481-493): get_next_chronic() sets the current id to 0, then the NEXT id is looked up in
+    // the OLD chronic's id list and loaded from the NEW chronic (quirk q2)
+    const HostChronic& old_ = e->chronics[s];
+    const HostChronic& nw = e->chronics[next[s]];
+    int i0 = index_of(old_.ids, 0);
+    int nid = old_.ids[std::min(std::max(i0, 0) + 1, old_.T - 1)];
+    int r_ = index_of(nw.ids, nid);
+    roll[s] = r_ < 0 ? std::min(1, nw.T - 1) : r_;
+    // hard game over (game.py:770-776): current id None -> get_next_chronic() (id 0) -> next id of the new chronic
+    const HostChronic& me = e->chronics[s];
+    int j0 = index_of(me.ids, 0);
+    restart[s] = std::min(std::max(j0, 0) + 1, me.T - 1);
+  }
+  DevCase& d = e->dc;
+  d.n_slots = ns;
+  d.c_pp = upload(e, pp, e->chronic_allocs); d.c_pv = upload(e, pv, e->chronic_allocs);
+  d.c_lp = upload(e, lp, e->chronic_allocs); d.c_lq = upload(e, lq, e->chronic_allocs);
+  d.c_ppp = upload(e, ppp, e->chronic_allocs); d.c_pvp = upload(e, pvp, e->chronic_allocs);
+  d.c_lpp = upload(e, lpp, e->chronic_allocs); d.c_lqp = upload(e, lqp, e->chronic_allocs);
+  d.c_mt = upload(e, mt, e->chronic_allocs); d.c_hz = upload(e, hz, e->chronic_allocs);
+  d.c_off = upload(e, off, e->chronic_allocs); d.c_T = upload(e, T, e->chronic_allocs);
+  d.c_next = upload(e, next, e->chronic_allocs); d.c_roll = upload(e, roll, e->chronic_allocs);
+  d.c_restart = upload(e, restart, e->chronic_allocs); d.c_dates = upload(e, dates, e->chronic_allocs);
+  if (!d.c_dates) return fail(e, PPN_E_HIP, "chronic upload failed: %s", dev_err());
+  e->chronics_dirty = false;
+  return PPN_OK;
+}
+
+static KArgs make_args(ppn_engine* e, bool sim_state) {
+  KArgs a;
+  memset(&a, 0, sizeof a);
+  a.d = e->dc;
+  a.st = sim_state ? e->sim : e->st;
+  return a;
+}
+
+extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* chronic_slot, const int32_t* t0) {
+  if (!e) return PPN_E_INVALID;
+  int rc = sync_chronics(e);
+  if (rc) return rc;
+  if (!env_ids) n = e->batch;
+  if (n <= 0 || n > e->batch) return fail(e, PPN_E_INVALID, "ppn_reset: bad environment count");
+  const int ns = (int)e->chronics.size();
+  std::vector<int> buf((size_t)3 * e->batch, 0);
+  for (int k = 0; k < n; ++k) {
+    const int env = env_ids ? env_ids[k] : k;
+    if (env < 0 || env >= e->batch) return fail(e, PPN_E_INVALID, "ppn_reset: environment id out of range");
+    const int s = chronic_slot ? chronic_slot[k] : 0;
+    if (s < 0 || s >= ns) return fail(e, PPN_E_INVALID, "ppn_reset: chronic slot %d not loaded", s);
+    const int t = t0 ? t0[k] : 0;
+    if (t < 0 || t >= e->chronics[s].T) return fail(e, PPN_E_INVALID, "ppn_reset: t0 out of range");
+    buf[k] = env; buf[e->batch + k] = s; buf[2 * e->batch + k] = t;
+  }
+  if (dev_h2d(e->d_ids, buf.data(), buf.size() * sizeof(int), e->stream)) return fail(e, PPN_E_HIP, "ppn_reset upload failed");
+  KArgs a = make_args(e, false);
+  a.ids = e->d_ids; a.slots = e->d_ids + e->batch; a.t0 = e->d_ids + 2 * e->batch;
+  if (launch<K_RESET>(e, a, n)) return fail(e, PPN_E_HIP, "reset kernel launch failed: %s", dev_err());
+  return PPN_OK;
+}
+
+static int copy_state(ppn_engine* e, DevState* dst, const DevState* src) {
+  const DevCase& d = e->dc;
+  const size_t B = e->batch;
+  int rc = 0;
+#define CP(m, type, n) rc |= dev_d2d(dst->m, src->m, sizeof(type) * B * (n), e->stream);
+  CP(vm, double, d.nrows) CP(va, double, d.nrows) CP(pg, double, d.nP) CP(qg, double, d.nP) CP(vg, double, d.nP)
+  CP(pd, double, d.nL) CP(qd, double, d.nL) CP(pf, double, d.nl) CP(qf, double, d.nl) CP(pt, double, d.nl)
+  CP(qt, double, d.nl) CP(amps, double, d.nl) CP(pn, u8, d.nP) CP(ln, u8, d.nL) CP(on, u8, d.nl) CP(en, u8, d.nl)
+  CP(st, u8, d.nl) CP(rec, int, d.nl) CP(lcd, int, d.nl) CP(ncd, int, d.nS) CP(soft, int, d.nl)
+  CP(done, u8, 1) CP(dead, u8, 1) CP(succ, u8, 1) CP(btype, u8, d.nrows) CP(flag, int, 1) CP(ill, int, 1)
+  CP(depth, int, 1) CP(nsolve, int, 1) CP(niter, int, 1) CP(slot, int, 1) CP(row, int, 1) CP(nlc, int, 1)
+  CP(npc, int, 1) CP(epoch, int, 1)
+#undef CP
+  return rc;
+}
+
+extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
+                        int32_t auto_reset) {
+  if (!e || !actions) return PPN_E_INVALID;
+  if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
+  const u8* dact = actions;
+  if (!actions_on_device) {
+    if (dev_h2d(e->d_actions, actions, (size_t)e->batch * e->dc.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
+    dact = e->d_actions;
+  }
+  if (simulate) { if (copy_state(e, &e->sim, &e->st)) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err()); }
+  KArgs a = make_args(e, simulate != 0);
+  a.actions = dact; a.sim = simulate ? 1 : 0;
+  if (launch<K_STEP>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  if (auto_reset && !simulate) {
+    if (launch<K_GAMEOVER>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "game-over kernel launch failed: %s", dev_err());
+  }
+  return PPN_OK;
+}
+
+extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
+  if (!e) return PPN_E_INVALID;
+  if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
+  KArgs a = make_args(e, false);
+  if (env_mask) {
+    if (dev_h2d(e->d_valid, env_mask, e->batch, e->stream)) return fail(e, PPN_E_HIP, "mask upload failed");
+    a.valid = e->d_valid;
+  }
+  if (launch<K_GAMEOVER>(e, a, e->batch)) return fail(e, PPN_E_HIP, "game-over kernel launch failed: %s", dev_err());
+  return PPN_OK;
+}
+
+extern "C" int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_t* valid) {
+  if (!e || !actions || !valid) return PPN_E_INVALID;
+  if (dev_h2d(e->d_actions, actions, (size_t)e->batch * e->dc.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
+  KArgs a = make_args(e, false);
+  a.actions = e->d_actions; a.valid = e->d_valid;
+  if (launch<K_VALID>(e, a, e->batch)) return fail(e, PPN_E_HIP, "kernel launch failed: %s", dev_err());
+  if (dev_d2h(valid, e->d_valid, e->batch, e->stream)) return fail(e, PPN_E_HIP, "download failed: %s", dev_err());
+  return PPN_OK;
+}
+
+extern "C" int ppn_runpf_batch(ppn_engine* e) {
+  if (!e) return PPN_E_INVALID;
+  KArgs a = make_args(e, false);
+  if (launch<K_RUNPF>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "runpf kernel launch failed: %s", dev_err());
+  return PPN_OK;
+}
+
+extern "C" int ppn_sync(ppn_engine* e) {
+  if (!e) return PPN_E_INVALID;
+#ifndef PPN_EMU
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
+#endif
+  return PPN_OK;
+}
+
+extern "C" void* ppn_stream(ppn_engine* e) {
+#ifdef PPN_EMU
+  (void)e; return nullptr;
+#else
+  return e ? (void*)e->stream : nullptr;
+#endif
+}
+
+extern "C" int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, int64_t* launches) {
+  if (!e) return PPN_E_INVALID;
+#ifndef PPN_EMU
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
+  for (size_t k = 0; k + 1 < e->ev_used; k += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev[k], e->ev[k + 1]) == hipSuccess) e->time_ms += ms;
+  }
+  e->ev_used = 0;
+#endif
+  if (total_ms) *total_ms = e->time_ms;
+  if (launches) *launches = e->launches;
+  if (reset) { e->time_ms = 0.0; e->launches = 0; }
+  return PPN_OK;
+}
+
+extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation) {
+  if (!e || !dst) return PPN_E_INVALID;
+  const DevState& s = from_simulation ? e->sim : e->st;
+  const size_t B = e->batch;
+  if (f == PPN_F_OBSERVATION) {
+    const size_t need = B * e->dc.obslen * sizeof(double);
+    if (bytes < need) return fail(e, PPN_E_INVALID, "ppn_read: buffer too small (%zu < %zu)", bytes, need);
+    if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
+    KArgs a = make_args(e, from_simulation != 0);
+    a.obs = to_host ? e->d_obs : (double*)dst;
+    if (launch<K_OBS>(e, a, e->batch)) return fail(e, PPN_E_HIP, "observation kernel launch failed: %s", dev_err());
+    if (to_host && dev_d2h(dst, e->d_obs, need, e->stream)) return fail(e, PPN_E_HIP, "download failed: %s", dev_err());
+    return PPN_OK;
+  }
+  FieldInfo fi; bool w;
+  if (!field_info(e, f, &fi, &w)) return fail(e, PPN_E_INVALID, "ppn_read: unknown field %d", (int)f);
+  const size_t need = fi.elem * fi.n * B;
+  if (bytes < need) return fail(e, PPN_E_INVALID, "ppn_read: buffer too small (%zu < %zu)", bytes, need);
+  void* src = *(void**)((char*)&s + fi.off);
+  const int rc = to_host ? dev_d2h(dst, src, need, e->stream) : dev_d2d(dst, src, need, e->stream);
+  return rc ? fail(e, PPN_E_HIP, "ppn_read copy failed: %s", dev_err()) : PPN_OK;
+}
+
+extern "C" int ppn_write(ppn_engine* e, ppn_field f, const void* src, size_t bytes) {
+  if (!e || !src) return PPN_E_INVALID;
+  FieldInfo fi; bool w;
+  if (!field_info(e, f, &fi, &w) || !w) return fail(e, PPN_E_INVALID, "ppn_write: field %d is not writable", (int)f);
+  const size_t need = fi.elem * fi.n * (size_t)e->batch;
+  if (bytes != need) return fail(e, PPN_E_INVALID, "ppn_write: expected %zu bytes, got %zu", need, bytes);
+  void* dst = *(void**)((char*)&e->st + fi.off);
+  return dev_h2d(dst, src, need, e->stream) ? fail(e, PPN_E_HIP, "ppn_write copy failed: %s", dev_err()) : PPN_OK;
+}

@@ -1,0 +1,223 @@
+"""Batched load-flow step engine: thin numpy-facing wrapper over the C ABI (include/ppn.h).
+
+``Engine`` owns B independent grids on one GPU.  It replaces, for the whole batch at once, what one reference
+``Game`` + ``Grid`` pair does per environment (pypownet/game.py, pypownet/grid.py): ``reset`` = Game.__init__'s
+first load + cascade, ``step`` = Game.step, ``simulate`` = Game.simulate, ``process_game_over``,
+``runpf`` = the bare pypower.runpf call.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .case import Case
+
+MODE_AC, MODE_DC = 0, 1
+SOLVER_NEWTON, SOLVER_FDXB = 1, 2
+FLAG_OK, FLAG_DIVERGED, FLAG_TOO_MANY_LOADS, FLAG_TOO_MANY_PRODS, FLAG_ENGINE_CAPACITY = 0, 1, 2, 3, 4
+ILL_TOO_MANY, ILL_BROKEN_LINE, ILL_LINE_COOLDOWN, ILL_NODE_COOLDOWN = 1, 2, 4, 8
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def rules_from_conf(conf, without_overflow_cutoff=False, game_over_mode='soft', looping_mode='natural',
+                    max_active_buses=0, lu_capacity=0):
+    """Build the ppn_rules struct from a parsed configuration.yaml (pypownet/parameters.py keys)."""
+    r = _lib.PpnRules()
+    r.mode = MODE_DC if str(conf.get('loadflow_mode', 'AC')).lower() == 'dc' else MODE_AC
+    solver = str(conf.get('solver', 'fdxb')).lower()
+    r.solver = SOLVER_NEWTON if solver == 'newton' else SOLVER_FDXB
+    r.tol = float(conf.get('tol', 1e-6))
+    r.max_it = int(conf.get('max_it', 10 if r.solver == SOLVER_NEWTON else 25))
+    r.hard_overflow_coefficient = 1e9 if without_overflow_cutoff else float(conf['hard_overflow_coefficient'])
+    r.n_timesteps_hard_overflow_is_broken = int(conf['n_timesteps_hard_overflow_is_broken'])
+    r.n_timesteps_consecutive_soft_overflow_breaks = 1e12 if without_overflow_cutoff else float(
+        conf['n_timesteps_consecutive_soft_overflow_breaks'])
+    r.n_timesteps_soft_overflow_is_broken = int(conf['n_timesteps_soft_overflow_is_broken'])
+    r.n_timesteps_horizon_maintenance = int(conf['n_timesteps_horizon_maintenance'])
+    r.max_number_prods_game_over = int(conf['max_number_prods_game_over'])
+    r.max_number_loads_game_over = int(conf['max_number_loads_game_over'])
+    r.n_timesteps_actionned_line_reactionable = int(conf['n_timesteps_actionned_line_reactionable'])
+    r.n_timesteps_actionned_node_reactionable = int(conf['n_timesteps_actionned_node_reactionable'])
+    r.max_number_actionned_substations = int(conf['max_number_actionned_substations'])
+    r.max_number_actionned_lines = int(conf['max_number_actionned_lines'])
+    r.max_number_actionned_total = int(conf['max_number_actionned_total'])
+    r.game_over_mode_hard = 1 if game_over_mode == 'hard' else 0
+    if looping_mode not in ('natural', 'fixed'):
+        raise ValueError('the batched engine supports chronic looping modes "natural" and "fixed"')
+    r.chronic_looping = 0 if looping_mode == 'natural' else 1
+    r.max_active_buses = int(max_active_buses)
+    r.lu_capacity = int(lu_capacity)
+    return r
+
+
+class Engine(object):
+    def __init__(self, case, conf, batch, device=0, chronics=None, thermal_limits=None, _lib_path=None, **rule_kw):
+        self._lib = _lib.load_library(_lib_path)
+        self.case = case if isinstance(case, Case) else Case(case)
+        self.batch = int(batch)
+        ppc = self.case.ppc
+        self._bus = np.ascontiguousarray(ppc['bus'], dtype=np.float64)
+        self._gen = np.ascontiguousarray(ppc['gen'], dtype=np.float64)
+        self._branch = np.ascontiguousarray(ppc['branch'], dtype=np.float64)
+        pc = _lib.PpnCase()
+        pc.n_bus_rows, pc.bus_cols = self._bus.shape
+        pc.n_gen, pc.gen_cols = self._gen.shape
+        pc.n_branch, pc.branch_cols = self._branch.shape
+        pc.base_mva = float(ppc['baseMVA'])
+        dp = C.POINTER(C.c_double)
+        pc.bus, pc.gen, pc.branch = self._bus.ctypes.data_as(dp), self._gen.ctypes.data_as(dp), \
+            self._branch.ctypes.data_as(dp)
+        self.rules = rules_from_conf(conf, **rule_kw)
+        h = C.c_void_p()
+        rc = self._lib.ppn_create(C.byref(pc), C.byref(self.rules), self.batch, int(device), C.byref(h))
+        if rc != 0:
+            raise EngineError('ppn_create failed (%d): %s' % (rc, self._lib.ppn_last_error(None).decode()))
+        self._h = h
+        self.n_chronics = 0
+        if chronics:
+            for ch in chronics:
+                self.load_chronic(ch)
+            limits = chronics[0].get_imaps() if thermal_limits is None else thermal_limits
+            self.set_thermal_limits(limits)
+        elif thermal_limits is not None:
+            self.set_thermal_limits(thermal_limits)
+
+    # ---- plumbing -----------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError('%s failed (%d): %s' % (what, rc, self._lib.ppn_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.ppn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dim(self, which):
+        return int(self._lib.ppn_dim(self._h, which))
+
+    @property
+    def lds_bytes(self):
+        return self.dim(7)
+
+    # ---- data ---------------------------------------------------------------------------------------
+    def set_thermal_limits(self, limits):
+        a = np.ascontiguousarray(limits, dtype=np.float64)
+        assert a.shape == (self.case.nl,)
+        self.thermal_limits = a
+        self._check(self._lib.ppn_set_thermal_limits(self._h, a.ctypes.data_as(C.POINTER(C.c_double))), 'ppn_set_thermal_limits')
+
+    def load_chronic(self, ch):
+        """Upload a pypownet_amd.chronic.Chronic into the next slot."""
+        T = ch.n_timesteps
+        c = _lib.PpnChronic()
+        c.T = T
+        keep = []
+        fp = C.POINTER(C.c_float)
+
+        def f32(a, n):
+            a = np.ascontiguousarray(np.asarray(a)[:T].reshape(T, n), dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data_as(fp)
+        cs = self.case
+        c.prods_p, c.prods_v = f32(ch.prods_p, cs.nP), f32(ch.prods_v, cs.nP)
+        c.loads_p, c.loads_q = f32(ch.loads_p, cs.nL), f32(ch.loads_q, cs.nL)
+        c.prods_p_planned, c.prods_v_planned = f32(ch.prods_p_planned, cs.nP), f32(ch.prods_v_planned, cs.nP)
+        c.loads_p_planned, c.loads_q_planned = f32(ch.loads_p_planned, cs.nL), f32(ch.loads_q_planned, cs.nL)
+        c.maintenance, c.hazards = f32(ch.maintenance, cs.nl), f32(ch.hazards, cs.nl)
+        ids = np.ascontiguousarray(ch.timestep_ids[:T], dtype=np.int32)
+        dates = np.ascontiguousarray(ch.date_fields(), dtype=np.int32)
+        keep += [ids, dates]
+        c.ids = ids.ctypes.data_as(C.POINTER(C.c_int32))
+        c.dates = dates.ctypes.data_as(C.POINTER(C.c_int32))
+        self._check(self._lib.ppn_load_chronic(self._h, self.n_chronics, C.byref(c)), 'ppn_load_chronic')
+        self.n_chronics += 1
+
+    # ---- game ---------------------------------------------------------------------------------------
+    def reset(self, env_ids=None, chronic_slot=None, t0=None):
+        ip = C.POINTER(C.c_int32)
+        n = self.batch if env_ids is None else len(env_ids)
+
+        def arr(a):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.int32), (n,)))
+            return a, a.ctypes.data_as(ip)
+        e, ep = arr(env_ids)
+        s, sp = arr(chronic_slot)
+        t, tp = arr(t0)
+        self._check(self._lib.ppn_reset(self._h, ep, n, sp, tp), 'ppn_reset')
+
+    def _actions(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions).reshape(self.batch, self.case.action_length) != 0, dtype=np.uint8)
+        return a
+
+    def step(self, actions, auto_reset=False):
+        a = self._actions(actions)
+        self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 0, 1 if auto_reset else 0), 'ppn_step')
+
+    def step_device(self, actions_ptr, auto_reset=False):
+        """actions_ptr: device address of a uint8 [batch x action_len] buffer (e.g. torch_tensor.data_ptr())."""
+        self._check(self._lib.ppn_step(self._h, C.c_void_p(int(actions_ptr)), 1, 0, 1 if auto_reset else 0), 'ppn_step')
+
+    def simulate(self, actions):
+        a = self._actions(actions)
+        self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 1, 0), 'ppn_step(simulate)')
+
+    def process_game_over(self, env_mask=None):
+        """Game.process_game_over for every dead environment, plus the live ones selected by env_mask."""
+        if env_mask is None:
+            self._check(self._lib.ppn_process_game_over(self._h, None), 'ppn_process_game_over')
+        else:
+            m = np.ascontiguousarray(np.broadcast_to(np.asarray(env_mask) != 0, (self.batch,)), dtype=np.uint8)
+            self._check(self._lib.ppn_process_game_over(self._h, m.ctypes.data), 'ppn_process_game_over')
+
+    def force_game_over(self):
+        self.process_game_over(np.ones(self.batch, dtype=np.uint8))
+
+    def is_action_valid(self, actions):
+        a = self._actions(actions)
+        out = np.zeros(self.batch, dtype=np.uint8)
+        self._check(self._lib.ppn_is_action_valid(self._h, a.ctypes.data, out.ctypes.data), 'ppn_is_action_valid')
+        return out.astype(bool)
+
+    def runpf(self):
+        self._check(self._lib.ppn_runpf_batch(self._h), 'ppn_runpf_batch')
+
+    def sync(self):
+        self._check(self._lib.ppn_sync(self._h), 'ppn_sync')
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        self._check(self._lib.ppn_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(n)), 'ppn_kernel_time')
+        return ms.value, n.value
+
+    # ---- state --------------------------------------------------------------------------------------
+    def read(self, name, simulation=False):
+        fid = _lib.FIELD_ID[name]
+        nbytes = int(self._lib.ppn_field_bytes(self._h, fid))
+        dt = np.dtype(_lib.field_dtype(name))
+        out = np.empty((self.batch, nbytes // dt.itemsize), dtype=dt)
+        self._check(self._lib.ppn_read(self._h, fid, out.ctypes.data, out.nbytes, 1, 1 if simulation else 0), 'ppn_read')
+        return out[:, 0] if out.shape[1] == 1 and name not in ('OBSERVATION',) and nbytes == dt.itemsize else out
+
+    def read_into_device(self, name, dev_ptr, nbytes, simulation=False):
+        fid = _lib.FIELD_ID[name]
+        self._check(self._lib.ppn_read(self._h, fid, C.c_void_p(int(dev_ptr)), nbytes, 0, 1 if simulation else 0), 'ppn_read')
+
+    def write(self, name, values):
+        fid = _lib.FIELD_ID[name]
+        dt = np.dtype(_lib.field_dtype(name))
+        a = np.ascontiguousarray(values, dtype=dt)
+        self._check(self._lib.ppn_write(self._h, fid, a.ctypes.data, a.nbytes), 'ppn_write')
+
+    def observations(self, simulation=False):
+        return self.read('OBSERVATION', simulation=simulation)

@@ -1,0 +1,155 @@
+"""Engine-vs-oracle checks shared by the CPU emulation tests and the GPU parity tests."""
+import numpy as np
+
+from helpers import (load_env, oracle_game, do_nothing, set_line_switch, set_substation_switches,
+                     nodes_of_substation, differential)
+from oracle.game_np import obs_as_array
+
+TOL_V = 1e-6      # p.u. / rad: the parity bar of BASELINE.json's north_star
+TOL_FLOW = 1e-4   # MW / MVAr / A
+
+
+def make_engine(lib_path, envname, batch, conf=None, **kw):
+    from pypownet_amd.engine import Engine
+    case, cfg, chronics = load_env(envname, conf=conf)
+    return Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, **kw), case, cfg, chronics
+
+
+def compare_state(eng, games, tol_v=1e-8):
+    vm, va = eng.read('VM'), eng.read('VA')
+    pg, qg = eng.read('PG'), eng.read('QG')
+    pf, qf, pt, qt = eng.read('PF'), eng.read('QF'), eng.read('PT'), eng.read('QT')
+    st = eng.read('LINES_STATUS')
+    bt = eng.read('BUS_TYPE')
+    rec, lcd, ncd, soft = (eng.read('RECONNECTABLE'), eng.read('LINE_COOLDOWN'), eng.read('NODE_COOLDOWN'),
+                           eng.read('SOFT_COUNT'))
+    pn, ln, on, en = (eng.read('PRODS_NODES'), eng.read('LOADS_NODES'), eng.read('LINES_OR_NODES'),
+                      eng.read('LINES_EX_NODES'))
+    for b, g in enumerate(games):
+        if g is None:
+            continue
+        act = g.bus_type != 4
+        assert np.array_equal(bt[b] != 4, act), 'isolated-bus mask differs (env %d)' % b
+        np.testing.assert_allclose(vm[b][act], g.vm[act], rtol=0, atol=tol_v)
+        np.testing.assert_allclose(np.deg2rad(va[b][act]), np.deg2rad(g.va[act]), rtol=0, atol=tol_v)
+        np.testing.assert_allclose(pg[b], g.pg, rtol=0, atol=TOL_FLOW)
+        np.testing.assert_allclose(qg[b], g.qg, rtol=0, atol=TOL_FLOW)
+        np.testing.assert_allclose(np.c_[pf[b], qf[b], pt[b], qt[b]], g.flows, rtol=0, atol=TOL_FLOW)
+        assert np.array_equal(st[b], g.line_status)
+        assert np.array_equal(pn[b], g.prods_nodes) and np.array_equal(ln[b], g.loads_nodes)
+        assert np.array_equal(on[b], g.or_nodes) and np.array_equal(en[b], g.ex_nodes)
+        assert np.array_equal(rec[b], g.reconnectable.astype(int))
+        assert np.array_equal(lcd[b], g.line_cooldown.astype(int))
+        assert np.array_equal(ncd[b], g.node_cooldown.astype(int))
+        assert np.array_equal(soft[b], g.n_soft_overflowed.astype(int))
+
+
+def lockstep(eng, games, actions_per_step, tol_v=1e-8, check_obs=False):
+    """Steps engine and oracles with the same actions (WrappedRunner protocol: a done env is passed through
+    process_game_over) and compares flags and full state after every step."""
+    case = games[0].case
+    B = len(games)
+    for t, acts in enumerate(actions_per_step):
+        acts = np.asarray(acts).reshape(B, case.action_length)
+        eng.step(acts)
+        done, flag, ill = eng.read('DONE'), eng.read('FLAG'), eng.read('ILLEGAL')
+        exp = [g.step(acts[b].copy()) for b, g in enumerate(games)]
+        for b, (o, f, i, d) in enumerate(exp):
+            assert bool(done[b]) == d, 'done differs at step %d env %d' % (t, b)
+            assert int(flag[b]) == f, 'flag differs at step %d env %d: %d vs %d' % (t, b, flag[b], f)
+            assert int(ill[b]) == i, 'illegal bits differ at step %d env %d' % (t, b)
+        alive = [None if exp[b][3] else g for b, g in enumerate(games)]
+        compare_state(eng, alive, tol_v)
+        if check_obs:
+            obs = eng.observations()
+            for b, g in enumerate(alive):
+                if g is not None:
+                    np.testing.assert_allclose(obs[b], obs_as_array(exp[b][0]), rtol=0, atol=TOL_FLOW)
+        if done.any():
+            eng.process_game_over()
+            for b, g in enumerate(games):
+                if exp[b][3]:
+                    g.process_game_over()
+            compare_state(eng, games, tol_v)
+
+
+def check_do_nothing(lib_path, env, solver, steps=12, batch=2):
+    eng, case, cfg, chronics = make_engine(lib_path, env, batch, conf={'solver': solver})
+    games = [oracle_game(env, conf={'solver': solver}) for _ in range(batch)]
+    eng.reset()
+    compare_state(eng, games)
+    lockstep(eng, games, [np.zeros((batch, case.action_length), dtype=np.uint8)] * steps, check_obs=True)
+
+
+def check_hard_overflow_scenario(lib_path, solver):
+    """K1 consequences (reference tests/test_core.py:968-976, 1423-1427) through the engine."""
+    env = 'default14_for_tests_hard_overflow'
+    eng, case, cfg, chronics = make_engine(lib_path, env, 1, conf={'solver': solver})
+    g = oracle_game(env, conf={'solver': solver})
+    eng.reset()
+    eng.write('SOFT_COUNT', eng.read('SOFT_COUNT'))     # exercise ppn_write round trip
+    # WrappedRunner: process_game_over first
+    eng2_done = eng.read('DONE')
+    assert not eng2_done.any()
+    # force the initial process_game_over of the reference harness on both sides
+    g.process_game_over()
+    _force_game_over(eng)
+    compare_state(eng, [g])
+    acts = []
+    for i in range(1, 16):
+        a = do_nothing(case)
+        if 9 <= i < 15:
+            set_line_switch(case, a, 6, 1)
+        acts.append(a[None, :])
+    ills = []
+    for a in acts:
+        eng.step(a)
+        o, f, il, d = g.step(a[0].copy())
+        assert int(eng.read('FLAG')[0]) == f == 0 and not d
+        assert int(eng.read('ILLEGAL')[0]) == il
+        ills.append(il)
+        compare_state(eng, [g])
+    assert [k for k, v in enumerate(ills) if v] == [8, 9, 11, 12]
+    assert list(eng.read('LINES_STATUS')[0]) == [1] * 20
+
+
+def _force_game_over(eng):
+    """Equivalent of calling RunEnv.process_game_over() on a live environment (the reference test harness does
+    that before every run): mark every environment dead, then process."""
+    # there is no public 'kill' in the ABI; emulate with an illegal... simplest: step is not needed --
+    # process_game_over only acts on dead environments, so use the dedicated test hook below.
+    eng.force_game_over()
+
+
+def check_topology_scenarios(lib_path, env, nodes, n_iter, policy_factory, solver='fdxb', conf=None):
+    cf = {'solver': solver}
+    if conf:
+        cf.update(conf)
+    B = len(nodes)
+    eng, case, cfg, chronics = make_engine(lib_path, env, B, conf=cf)
+    games = [oracle_game(env, conf=cf) for _ in nodes]
+    eng.reset()
+    for g in games:
+        g.process_game_over()
+    eng.force_game_over()
+    compare_state(eng, games)
+    policies = [policy_factory(case, node) for node in nodes]
+    obs = [g.export_observation() for g in games]
+    flags_seen = [[] for _ in nodes]
+    for i in range(1, n_iter + 1):
+        acts = np.stack([policies[b](i, obs[b]) for b in range(B)])
+        eng.step(acts)
+        done, flag, ill = eng.read('DONE'), eng.read('FLAG'), eng.read('ILLEGAL')
+        for b, g in enumerate(games):
+            o, f, il, d = g.step(acts[b].copy())
+            assert (bool(done[b]), int(flag[b]), int(ill[b])) == (d, f, il), (i, b, done[b], flag[b], ill[b], d, f, il)
+            flags_seen[b].append(f)
+            if d:
+                g.process_game_over()
+                obs[b] = g.export_observation()
+            else:
+                obs[b] = o
+        if done.any():
+            eng.process_game_over()
+        compare_state(eng, games)
+    return flags_seen

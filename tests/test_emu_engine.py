@@ -1,0 +1,64 @@
+"""CPU-side logic tests of the HIP kernels.  The kernel source (pypownet_amd/csrc/*.inc) is compiled here
+lane-serially with g++ (-DPPN_EMU) into build/libppn_emu.so -- a TEST-ONLY artefact that the package never loads --
+and driven through the very same C ABI and Python wrapper as the GPU library, then compared with the oracle.
+This is what lets host logic, the ABI plumbing and the game/solve control flow be checked without a GPU; the
+parity tests proper (tests/test_gpu_*.py, -m gpu) run the real gfx950 build."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import engine_checks as ec
+from helpers import ROOT
+from test_oracle_known_answers import _basic_topology_policy
+
+EMU = os.path.join(ROOT, 'build', 'libppn_emu.so')
+SRC = os.path.join(ROOT, 'pypownet_amd', 'csrc')
+
+
+@pytest.fixture(scope='session')
+def emu_lib():
+    srcs = [os.path.join(SRC, f) for f in os.listdir(SRC)] + [os.path.join(ROOT, 'include', 'ppn.h')]
+    if not os.path.exists(EMU) or any(os.path.getmtime(s) > os.path.getmtime(EMU) for s in srcs):
+        os.makedirs(os.path.dirname(EMU), exist_ok=True)
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-DPPN_EMU', '-fPIC', '-shared', '-x', 'c++',
+                               os.path.join(SRC, 'ppn_engine.hip'), '-o', EMU])
+    return EMU
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+@pytest.mark.parametrize('env', ['default14_for_tests', 'default14_for_tests_hard_overflow'])
+def test_emu_do_nothing_matches_oracle(emu_lib, env, solver):
+    ec.check_do_nothing(emu_lib, env, solver)
+
+
+def test_emu_dc_matches_oracle(emu_lib):
+    ec.check_do_nothing(emu_lib, 'default14_for_tests_beta', 'fdxb', steps=8, batch=1)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_emu_hard_overflow_scenario(emu_lib, solver):
+    ec.check_hard_overflow_scenario(emu_lib, solver)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_emu_k3_node_splitting_all_substations(emu_lib, solver):
+    nodes = list(range(1, 15))
+    flags = ec.check_topology_scenarios(emu_lib, 'default14_for_tests_alpha', nodes, 7, _basic_topology_policy, solver)
+    for node, f in zip(nodes, flags):
+        exp = [0] * 7
+        if node == 2:
+            exp[6] = 1
+        if node == 7:
+            exp[0] = 1
+        assert f == exp, (node, f)
+
+
+def test_emu_k3_dc(emu_lib):
+    nodes = list(range(1, 15))
+    ec.check_topology_scenarios(emu_lib, 'default14_for_tests_beta', nodes, 7, _basic_topology_policy)
+
+
+def test_emu_default118_few_steps(emu_lib):
+    ec.check_do_nothing(emu_lib, 'default118', 'newton', steps=3, batch=1)

@@ -1,0 +1,49 @@
+"""GPU parity tests (-m gpu): the gfx950 build of libppn.so, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Bars (BASELINE.json north_star): bit-exact line status / topology / counters / flags;
+|dVm| <= 1e-6 p.u. and |dVa| <= 1e-6 rad (measured margins are ~1e-10, the tests use 1e-8 where the two sides
+run the same algorithm)."""
+import numpy as np
+import pytest
+
+import engine_checks as ec
+from test_oracle_known_answers import _basic_topology_policy
+
+pytestmark = pytest.mark.gpu
+HIP = None   # default library path: pypownet_amd/libppn.so
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+@pytest.mark.parametrize('env', ['default14_for_tests', 'default14_for_tests_hard_overflow'])
+def test_gpu_do_nothing_matches_oracle(env, solver):
+    ec.check_do_nothing(HIP, env, solver, steps=12, batch=4)
+
+
+def test_gpu_dc_matches_oracle():
+    ec.check_do_nothing(HIP, 'default14_for_tests_beta', 'fdxb', steps=8, batch=2)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_hard_overflow_scenario(solver):
+    ec.check_hard_overflow_scenario(HIP, solver)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_k3_node_splitting_all_substations(solver):
+    nodes = list(range(1, 15))
+    flags = ec.check_topology_scenarios(HIP, 'default14_for_tests_alpha', nodes, 7, _basic_topology_policy, solver)
+    for node, f in zip(nodes, flags):
+        exp = [0] * 7
+        if node == 2:
+            exp[6] = 1
+        if node == 7:
+            exp[0] = 1
+        assert f == exp, (node, f)
+
+
+def test_gpu_k3_dc():
+    ec.check_topology_scenarios(HIP, 'default14_for_tests_beta', list(range(1, 15)), 7, _basic_topology_policy)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_default118_steps(solver):
+    ec.check_do_nothing(HIP, 'default118', solver, steps=6, batch=3)
