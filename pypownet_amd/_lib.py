@@ -59,13 +59,28 @@ EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limit
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version']
 
 
-def load_library(path=None):
+class _Prefixed(object):
+    """Attribute view that maps ppn_xxx onto <prefix>xxx (the test-suite drives the C oracle, which exports the
+    same signatures under orc_, through the same harness)."""
+
+    def __init__(self, lib, prefix):
+        self._lib, self._prefix = lib, prefix
+
+    def __getattr__(self, name):
+        if name.startswith('ppn_'):
+            return getattr(self._lib, self._prefix + name[4:])
+        return getattr(self._lib, name)
+
+
+def load_library(path=None, prefix='ppn_'):
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
             'pypownet_amd: the HIP extension %s is missing. Build it with `python __graft_entry__.py` '
             '(hipcc --offload-arch=gfx950); this engine has no CPU fallback.' % path)
     lib = C.CDLL(path)
+    if prefix != 'ppn_':
+        lib = _Prefixed(lib, prefix)
     vp = C.c_void_p
     lib.ppn_create.argtypes = [C.POINTER(PpnCase), C.POINTER(PpnRules), C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.ppn_create.restype = C.c_int

@@ -12,7 +12,8 @@ TOL_FLOW = 1e-4   # MW / MVAr / A
 def make_engine(lib_path, envname, batch, conf=None, **kw):
     from pypownet_amd.engine import Engine
     case, cfg, chronics = load_env(envname, conf=conf)
-    return Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, **kw), case, cfg, chronics
+    prefix = 'orc_' if (lib_path and 'liboracle' in lib_path) else 'ppn_'
+    return Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, _lib_prefix=prefix, **kw), case, cfg, chronics
 
 
 def compare_state(eng, games, tol_v=1e-8):
@@ -78,7 +79,8 @@ def check_do_nothing(lib_path, env, solver, steps=12, batch=2):
     games = [oracle_game(env, conf={'solver': solver}) for _ in range(batch)]
     eng.reset()
     compare_state(eng, games)
-    lockstep(eng, games, [np.zeros((batch, case.action_length), dtype=np.uint8)] * steps, check_obs=True)
+    lockstep(eng, games, [np.zeros((batch, case.action_length), dtype=np.uint8)] * steps,
+             check_obs=not (lib_path and 'liboracle' in lib_path))
 
 
 def check_hard_overflow_scenario(lib_path, solver):
