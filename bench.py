@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/s of the batched IEEE-118 AC load-flow step engine (BASELINE.json metric).
+
+One "step" = ppn_step(auto_reset=1) over the whole batch: every environment applies its (do-nothing) action,
+loads the next chronic row, runs the Newton-Raphson solve + the cascading-failure re-solve loop on the GPU,
+updates the game counters, and environments that ended the step in game over are passed through
+process_game_over -- all device resident, inputs (chronic tensors, state, actions) already in HBM.
+
+Workload (BASELINE.json configs[2], SURVEY.md 8d "config 3"): default118, AC Newton (tol 1e-6, <=10 its),
+4096 environments per GPU, do-nothing agent, thermal limits synthesised so that the cascade is exercised:
+limit_k = max(50, round(Q0.98_t I_k(t))) A (tools/make_bench_limits.py), hard coefficient 2.0, soft break after 3
+consecutive overflowed steps (default118 YAML).
+Environment e plays chronic (e mod n_chronics) from row t0 = (37 e) mod T.
+
+Usage: python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with torch.distributed.run.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+ENV_NAME = 'default118'
+BATCH_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
+B_IO = 21.6e3                    # compulsory per-step state bytes @118
+B_IT_NR = 72.0e3                 # streaming-model bytes per Newton iteration @118
+
+
+def load_workload():
+    import yaml
+    from pypownet_amd.case import Case
+    from pypownet_amd.chronic import Chronic
+    d = os.path.join(ROOT, 'tests', 'golden', 'envs', ENV_NAME, 'level0')
+    case = Case.from_file(os.path.join(d, 'reference_grid.json'))
+    with open(os.path.join(d, 'configuration.yaml')) as f:
+        conf = yaml.safe_load(f)
+    conf['solver'] = 'newton'
+    cdir = os.path.join(d, 'chronics')
+    chronics = [Chronic(os.path.join(cdir, c)) for c in sorted(os.listdir(cdir))]
+    return case, conf, chronics
+
+
+def bench_limits(case):
+    """Frozen synthetic limits of the workload (rule and generator: tools/make_bench_limits.py)."""
+    with open(os.path.join(ROOT, 'tests', 'golden', 'envs', ENV_NAME, 'bench_limits.json')) as f:
+        lim = np.asarray(json.load(f)['limits_a'], dtype=np.float64)
+    assert lim.shape == (case.nl,)
+    return lim
+
+
+def env_assignment(first, count, chronics):
+    ids = np.arange(first, first + count)
+    slots = (ids % len(chronics)).astype(np.int32)
+    T = np.array([c.n_timesteps for c in chronics])[slots]
+    t0 = ((ids * 37) % T).astype(np.int32)
+    return slots, t0
+
+
+def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
+    """C oracle (oracle/ppn_oracle.c, OpenMP over environments) on a bounded sample of the same workload."""
+    import subprocess
+    from pypownet_amd.engine import Engine
+    lib = os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')
+    if not os.path.exists(lib):
+        try:
+            subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
+        except Exception:
+            return None
+    cores = os.cpu_count() or 1
+    nb = max(256, 16 * cores)
+    eng = Engine(case, conf, nb, chronics=chronics, thermal_limits=limits, _lib_path=lib, _lib_prefix='orc_')
+    threads = max(1, eng.dim(12))
+    slots, t0 = env_assignment(0, nb, chronics)
+    eng.reset(chronic_slot=slots, t0=t0)
+    act = np.zeros((nb, case.action_length), dtype=np.uint8)
+    eng.step(act, auto_reset=True)
+    t = time.perf_counter()
+    steps = 0
+    while True:
+        eng.step(act, auto_reset=True)
+        steps += 1
+        el = time.perf_counter() - t
+        if el > budget_s or steps >= 4000:
+            break
+    return {'value': nb * steps / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle with OpenMP over envs' % (nb, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL over xGMI
+
+    from pypownet_amd.engine import Engine
+    case, conf, chronics = load_workload()
+    limits = bench_limits(case)
+    B = args.batch
+    eng = Engine(case, conf, B, device=local_rank, chronics=chronics, thermal_limits=limits, max_active_buses=128)
+    slots, t0 = env_assignment(rank * B, B, chronics)
+    eng.reset(chronic_slot=slots, t0=t0)
+    actions = torch.zeros((B, case.action_length), dtype=torch.uint8, device='cuda:%d' % local_rank)
+    torch.cuda.synchronize()
+    aptr = actions.data_ptr()
+
+    for _ in range(args.warmup):
+        eng.step_device(aptr, auto_reset=True)
+    eng.sync()
+    ns0, ni0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
+    eng.kernel_time(reset=True)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.sync()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step_device(aptr, auto_reset=True)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+
+    kms, klaunch = eng.kernel_time(reset=True)
+    ns1, ni1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
+    done_now = int(eng.read('DONE').sum())
+    stats = torch.tensor([elapsed, float(ns1 - ns0), float(ni1 - ni0), kms, float(klaunch)], dtype=torch.float64,
+                         device='cuda:%d' % local_rank)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        n_solves, n_iters = float(sm[1]), float(sm[2])
+    else:
+        n_solves, n_iters = float(stats[1]), float(stats[2])
+
+    if rank == 0:
+        total_steps = B * world * args.steps
+        solves_per_step = n_solves / total_steps
+        iters_per_solve = n_iters / max(n_solves, 1.0)
+        b_step = B_IO + solves_per_step * iters_per_solve * B_IT_NR          # algorithmic bytes per env-step
+        avg_kernel_s = (kms / 1e3) / max(klaunch, 1)                          # rank 0's step kernel, HIP events
+        achieved = B * b_step / avg_kernel_s / 1e9 if avg_kernel_s > 0 else None
+        out = {
+            'metric': 'env steps/sec, batched IEEE-118 AC load-flow',
+            'value': total_steps / elapsed,
+            'unit': 'env-steps/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic: IEEE-118 case + reference chronic series (fixture), synthetic thermal limits',
+            'config': {'workload': 'default118 AC Newton-Raphson (tol 1e-6), batch=%d envs/GPU with cascading-failure '
+                                   'inner loop, do-nothing agent, auto game-over reset' % B,
+                       'batch_per_gpu': B, 'solver': 'newton', 'parallelism': 'env-sharded x%d, no collective in the '
+                                                                              'step loop' % world,
+                       'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
+                       'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                         'kernel': 'ppn_kernel<W=2,K_STEP>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
+                         'algorithmic_bytes_per_env_step': b_step},
+            'cpu_baseline': None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(case, conf, chronics, limits)
+            except Exception as ex:   # the baseline must never take the bench line down
+                out['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port',
+                                       'sample': 'failed: %s' % ex}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

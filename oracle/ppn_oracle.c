@@ -38,7 +38,7 @@
 
 typedef double complex cplx;
 
-#define MAXDEG 96
+#define MAXDEG 48
 
 typedef struct {
   int n;            /* dimension */
@@ -81,6 +81,24 @@ struct orc_engine {
 };
 typedef struct orc_engine orc_engine;
 
+
+/* Per-thread bump arena for the per-solve scratch (malloc/calloc of ~1 MB per solve would dominate the run). */
+#define ARENA_BYTES ((size_t)24 << 20)
+static __thread char* t_arena = NULL;
+static __thread size_t t_off = 0;
+static void* a_alloc(size_t bytes, int zero) {
+  if (!t_arena) t_arena = (char*)malloc(ARENA_BYTES);
+  bytes = (bytes + 63) & ~(size_t)63;
+  if (t_off + bytes > ARENA_BYTES) { fprintf(stderr, "oracle arena exhausted\n"); abort(); }
+  void* p = t_arena + t_off;
+  t_off += bytes;
+  if (zero) memset(p, 0, bytes);
+  return p;
+}
+#define malloc(n) a_alloc((n), 0)
+#define calloc(n, m) a_alloc((size_t)(n) * (size_t)(m), 1)
+#define free(p) ((void)(p))
+
 /* ------------------------------------------------------------------------------------------------------ */
 static void rm_init(RowMat* m, int n) {
   m->n = n;
@@ -106,7 +124,7 @@ typedef struct {
   int *ucnt, *ucol; double* uval;    /* upper part incl. diagonal first */
   int* perm; int* pos;
 } SpLU;
-#define LUDEG 160
+#define LUDEG 96
 
 static void lu_init(SpLU* f, int n) {
   f->n = n;
@@ -213,6 +231,7 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
   const int nS = c->nS, nrows = c->nrows, nl = c->nl, nP = c->nP, nL = c->nL;
   const ppn_rules* R = &c->R;
   *iters = 0;
+  t_off = 0;   /* release the previous solve's scratch */
   /* isolated rows (grid.py:197-204) */
   char* touched = (char*)calloc(nrows, 1);
   for (int l = 0; l < nl; ++l) if (e->st[l]) { touched[c->or_sub[l] + e->on[l] * nS] = 1; touched[c->ex_sub[l] + e->en[l] * nS] = 1; }
@@ -490,6 +509,10 @@ done:
   if (Y.deg) { free(Y.deg); free(Y.col); free(Y.val); }
   return rc;
 }
+
+#undef malloc
+#undef calloc
+#undef free
 
 /* ------------------------------------------------------------------------------------------------------ */
 static int flag_of(int rc) { return rc == 0 ? 0 : (rc == 4 ? 4 : 1); }
