@@ -34,6 +34,15 @@ __device__ __forceinline__ int ppn_popc(u64 x) { return __popcll(x); }
 __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #endif
 
+// phase profiling (tools/profile_phases.py builds a separate libppn_prof.so with -DPPN_PROF)
+#if defined(PPN_PROF) && !defined(PPN_EMU)
+#define PROF_BEGIN() long long t_prof_ = clock64()
+#define PROF_MARK(E_, id) do { const long long t2_ = clock64(); if (lane0 == 0) (E_).prof[id] += t2_ - t_prof_; t_prof_ = clock64(); } while (0)
+#else
+#define PROF_BEGIN() ((void)0)
+#define PROF_MARK(E_, id) ((void)0)
+#endif
+
 #define PPN_NONE 0xFFFFu
 #define PPN_PI 3.14159265358979323846
 
@@ -88,6 +97,7 @@ struct DevState {
   int *rec, *lcd, *ncd, *soft;     // counters
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
+  long long* prof;                 // [16] cycle counters per phase (only written by -DPPN_PROF builds)
 };
 
 // LDS carve-up (pointers into the workgroup's dynamic shared memory)

@@ -284,13 +284,17 @@ static int alloc_state(ppn_engine* e, DevState* s) {
   s->flag = dalloc<int>(e, B); s->ill = dalloc<int>(e, B); s->depth = dalloc<int>(e, B);
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
-  return s->epoch ? 0 : -1;
+  s->prof = dalloc<long long>(e, B * 16);
+  return s->prof ? 0 : -1;
 }
 
 struct FieldInfo { size_t elem; int n; size_t off; };   // off: byte offset of the pointer inside DevState
 
 static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* writable) {
   const DevCase& d = e->dc;
+  if ((int)f == 100) {   /* phase cycle counters of -DPPN_PROF builds (tools/profile_phases.py) */
+    fi->elem = sizeof(long long); fi->n = 16; fi->off = offsetof(DevState, prof); *writable = true; return true;
+  }
 #define FI(member, type, count, w) { fi->elem = sizeof(type); fi->n = (count); fi->off = offsetof(DevState, member); *writable = (w); return true; }
   switch (f) {
     case PPN_F_VM: FI(vm, double, d.nrows, true)

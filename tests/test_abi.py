@@ -1,0 +1,83 @@
+"""CPU checks of the drop-in boundary: libppn.so (built by __graft_entry__.build()) loads, exports every symbol
+include/ppn.h declares, and fails loudly -- no silent CPU fallback -- when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, load_env
+
+HEADER = os.path.join(ROOT, 'include', 'ppn.h')
+
+
+@pytest.fixture(scope='session')
+def lib():
+    import __graft_entry__ as g
+    g.build_hip()
+    from pypownet_amd import _lib
+    return _lib.load_library()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r'\b(ppn_[a-z_]+)\s*\(', src)))
+
+
+def test_header_and_binding_agree(lib):
+    from pypownet_amd import _lib
+    decl = declared_symbols()
+    assert set(decl) == set(_lib.EXPORTS), (set(decl) ^ set(_lib.EXPORTS))
+    for s in decl:
+        assert hasattr(lib, s), 'libppn.so does not export %s' % s
+
+
+def test_field_enum_matches_header():
+    from pypownet_amd import _lib
+    src = open(HEADER).read()
+    body = src[src.index('typedef enum ppn_field'):src.index('} ppn_field;')]
+    names = re.findall(r'PPN_F_([A-Z_]+)', re.sub(r'/\*.*?\*/', '', body, flags=re.S))
+    names = [n for n in names if n != 'COUNT']
+    assert names == _lib.FIELDS
+
+
+def test_struct_sizes_match_c_layout():
+    """ctypes mirrors of ppn_rules / ppn_case / ppn_chronic must have the C layout (checked with gcc)."""
+    import subprocess
+    import tempfile
+    from pypownet_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "ppn.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(ppn_case), sizeof(ppn_rules), sizeof(ppn_chronic),
+         offsetof(ppn_rules, n_timesteps_consecutive_soft_overflow_breaks), offsetof(ppn_rules, lu_capacity));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(prog)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')])
+        out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
+    got = [C.sizeof(_lib.PpnCase), C.sizeof(_lib.PpnRules), C.sizeof(_lib.PpnChronic),
+           _lib.PpnRules.n_timesteps_consecutive_soft_overflow_breaks.offset, _lib.PpnRules.lu_capacity.offset]
+    assert [int(v) for v in out] == got
+
+
+def test_no_gpu_is_a_loud_error(lib):
+    """In the build container there is no GPU: ppn_create must refuse (PPN_E_NODEVICE), never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible here')
+    from pypownet_amd.engine import Engine, EngineError
+    case, cfg, chronics = load_env('default14_for_tests')
+    with pytest.raises(EngineError) as ei:
+        Engine(case, cfg, 2, chronics=chronics)
+    assert 'no HIP device' in str(ei.value) or 'failed' in str(ei.value)
+
+
+def test_missing_extension_raises(tmp_path):
+    from pypownet_amd import _lib
+    with pytest.raises(ImportError):
+        _lib.load_library(str(tmp_path / 'libppn_missing.so'))

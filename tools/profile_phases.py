@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of the step kernel (GPU box).  Builds pypownet_amd/csrc with -DPPN_PROF into
+build/libppn_prof.so (never loaded by the product), runs the bench workload for a few steps and prints the share
+of wave cycles spent in each phase of solve_loadflow / body_step."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+NAMES = ['A-C types/compaction', 'adjacency', 'symbolic', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
+         'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)']
+
+
+def main():
+    import bench
+    from pypownet_amd.engine import Engine
+    from pypownet_amd import _lib
+    lib = os.path.join(ROOT, 'build', 'libppn_prof.so')
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    if not os.path.exists(lib) or os.environ.get('PPN_REBUILD'):
+      subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+                           '-DPPN_PROF', os.path.join(ROOT, 'pypownet_amd', 'csrc', 'ppn_engine.hip'), '-o', lib])
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    case, conf, chronics = bench.load_workload()
+    eng = Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=128,
+                 _lib_path=lib)
+    slots, t0 = bench.env_assignment(0, B, chronics)
+    eng.reset(chronic_slot=slots, t0=t0)
+    act = np.zeros((B, case.action_length), dtype=np.uint8)
+    eng.step(act, auto_reset=True)
+    zero = np.zeros((B, 16), dtype=np.int64)
+    eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
+    s0, i0 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
+    for _ in range(steps):
+        eng.step(act, auto_reset=True)
+    eng.sync()
+    s1, i1 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
+    out = np.zeros((B, 16), dtype=np.int64)
+    eng._check(eng._lib.ppn_read(eng._h, 100, out.ctypes.data, out.nbytes, 1, 0), 'read prof')
+    tot = out.sum(axis=0).astype(np.float64)
+    nsolve, nit = float(s1 - s0), float(i1 - i0)
+    print('B=%d steps=%d solves=%d iterations=%d' % (B, steps, nsolve, nit))
+    for k, name in enumerate(NAMES):
+        per = tot[k] / (nit if k in (4, 5, 6) else nsolve)
+        print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, 'iteration' if k in (4, 5, 6) else 'solve'))
+
+
+if __name__ == '__main__':
+    main()
