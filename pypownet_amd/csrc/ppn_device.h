@@ -43,6 +43,16 @@ __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #define PROF_MARK(E_, id) ((void)0)
 #endif
 
+// LDS atomics (one wave per workgroup: conflicting lanes are serialised by the LDS unit in a fixed order, so
+// results are reproducible run to run)
+#ifdef PPN_EMU
+#define LDS_ADD(p, v) (*(p) += (v))
+#define LDS_OR(p, v) (*(p) |= (v))
+#else
+#define LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#define LDS_OR(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#endif
+
 #define PPN_NONE 0xFFFFu
 #define PPN_PI 3.14159265358979323846
 
@@ -72,6 +82,12 @@ struct DevCase {
   const double *ly;      // [nl*8]  yff.re, yff.im, yft.re, yft.im, ytf.re, ytf.im, ytt.re, ytt.im  (status on)
   const double *lb;      // [nl*10] B' (ff,ft,tf,tt), B'' (ff,ft,tf,tt), bdc, pfinj
   const int *pos_row;    // [nrows] bus row at elimination position p (static min-degree order, twins adjacent)
+  // static level schedule of the elimination forest of the base graph (valid for every topology obtained by line
+  // cuts and node splits): level of busbar (s,node) = 2*level(s) + node
+  const int *lvl_row;    // [nrows] bus rows sorted by (level, elimination position)
+  const int *lvl_start;  // [nlev+1] start of each level inside lvl_row
+  int nlev;
+  int MCAP, TCAP;        // schedule capacities: pivot-neighbour pairs, update triples
   const int *sub_le_ptr; // [nS+1]  CSR of line ends per substation
   const int *sub_le;     //         (line << 1) | end   (end 0 = origin, 1 = extremity)
   const int *elem_sub;   // [ntopo] substation of each element of [prods | loads | lines_or | lines_ex]
@@ -110,6 +126,9 @@ struct Smem {
   u8 *nv, *nv2, *touched, *hasgen, *genon;
   u8 *st, *on, *en, *pn, *ln, *subchg, *act, *over;
   int *red;
+  // per-solve elimination schedule
+  u8 *pvl, *kq, *mem, *mown, *tri, *ycol, *yrow;
+  u16 *moffq, *toffq, *lvlp, *lvlm, *lvlt, *jpos;
 };
 
 #ifdef PPN_EMU
@@ -138,6 +157,11 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) 
   PPN_TAKE(nv, u8, NB) PPN_TAKE(nv2, u8, NB) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
   PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
   PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen) PPN_TAKE(over, u8, nl) PPN_TAKE(red, int, 64 * 4)
+  PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
+  PPN_TAKE(tri, u8, 3 * (size_t)d.TCAP) PPN_TAKE(ycol, u8, (size_t)d.YCAP) PPN_TAKE(yrow, u8, (size_t)d.YCAP)
+  PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)
+  PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
+  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(jpos, u16, (size_t)d.YCAP * 2)
 #undef PPN_TAKE
   return o;
 }

@@ -450,7 +450,10 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   for (int p = 0; p < nS; ++p) { pos_row[2 * p] = order[p]; pos_row[2 * p + 1] = order[p] + nS; }
   std::vector<std::vector<char>> filled;
   const int pairs = filled_pairs(nS, or_sub, ex_sub, order, &filled);
-  // LU doubles of the Newton Jacobian with the case's own bus types (PV where a production sits, slack = ref)
+  // LU doubles of the Newton Jacobian with the case's own bus types (PV where a production sits, slack = ref),
+  // and the static level schedule of the elimination forest
+  std::vector<int> lvl_row(nrows), lvl_start;
+  int base_pairs = 0, base_tri = 0, nlev = 0;
   {
     std::vector<int> pos(nS), nvs(nS);
     for (int p = 0; p < nS; ++p) pos[order[p]] = p;
@@ -458,6 +461,23 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     int tot = 0;
     for (int i = 0; i < nS; ++i) for (int j = 0; j < nS; ++j) if (filled[i][j]) tot += nvs[i] * nvs[j];
     e->base_fill = tot;
+    std::vector<int> level(nS, 0);          // indexed by elimination position
+    for (int k = 0; k < nS; ++k) {
+      int c = 0;
+      for (int j = k + 1; j < nS; ++j) if (filled[k][j]) { ++c; level[j] = std::max(level[j], level[k] + 1); }
+      base_pairs += c; base_tri += c * c;
+    }
+    int maxl = 0;
+    for (int k = 0; k < nS; ++k) maxl = std::max(maxl, level[k]);
+    nlev = 2 * (maxl + 1);                   // busbar (s, node) sits in level 2*level(s) + node
+    lvl_start.assign(nlev + 1, 0);
+    int w = 0;
+    for (int lv = 0; lv < nlev; ++lv) {
+      lvl_start[lv] = w;
+      for (int p = 0; p < nS; ++p) if (2 * level[p] + 0 == lv) lvl_row[w++] = order[p];
+      for (int p = 0; p < nS; ++p) if (2 * level[p] + 1 == lv) lvl_row[w++] = order[p] + nS;
+    }
+    lvl_start[nlev] = w;
   }
   // sub -> line ends CSR
   std::vector<int> le_ptr(nS + 1, 0), le;
@@ -485,6 +505,14 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.NB = NB;
   e->W = (NB + 63) / 64;
   d.YCAP = NB + 2 * nl;
+  if (d.YCAP > 65000) d.YCAP = 65000;
+  d.nlev = nlev;
+  {
+    const double grow = (NB > nS) ? 3.0 : 1.5;   // node splitting adds busbars and fill
+    d.MCAP = ((int)(base_pairs * grow) + 64 + 15) & ~15;
+    d.TCAP = ((int)(base_tri * grow) + 256 + 15) & ~15;
+    if (d.MCAP > 65000 || d.TCAP > 21000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "schedule capacity exceeds 16-bit offsets"); }
+  }
   int lucap = r->lu_capacity;
   if (lucap <= 0) {
     lucap = (int)(e->base_fill * 1.30) + 192;
@@ -507,6 +535,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.gen_qmax = upload(e, qmax, e->allocs); d.gen_qmin = upload(e, qmin, e->allocs); d.gen_qg0 = upload(e, qg0, e->allocs);
   d.ly = upload(e, ly, e->allocs); d.lb = upload(e, lb, e->allocs);
   d.pos_row = upload(e, pos_row, e->allocs);
+  d.lvl_row = upload(e, lvl_row, e->allocs); d.lvl_start = upload(e, lvl_start, e->allocs);
   d.sub_le_ptr = upload(e, le_ptr, e->allocs); d.sub_le = upload(e, le, e->allocs);
   d.elem_sub = upload(e, elem_sub, e->allocs);
   d.status0 = upload(e, status0, e->allocs);
