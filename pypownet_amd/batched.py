@@ -1,0 +1,106 @@
+"""BatchedRunEnv: B independent pypownet environments on one GPU, sharded over the GPUs of a node.
+
+The load-flow step has NO exchange between environments, so the multi-GPU layout is a plain
+contiguous split of the global batch: rank r owns environments [r*B/W, (r+1)*B/W) and steps them with its own
+engine; there is no collective inside the step loop.  ``torch.distributed`` (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests) is only used by ``gather_to_root`` / ``all_reduce_stats`` when a single
+controller wants the results of every shard.
+"""
+import os
+
+import numpy as np
+import yaml
+
+from .case import Case
+from .chronic import Chronic
+from .engine import Engine
+
+
+def shard_range(global_batch, rank, world_size):
+    """Contiguous split; the first (global_batch % world_size) ranks own one extra environment."""
+    base, extra = divmod(int(global_batch), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def default_assignment(env_ids, chronics):
+    """environment e plays chronic (e mod n) from row (37 e) mod T."""
+    env_ids = np.asarray(env_ids)
+    slots = (env_ids % len(chronics)).astype(np.int32)
+    T = np.array([c.n_timesteps for c in chronics])[slots]
+    return slots, ((env_ids * 37) % T).astype(np.int32)
+
+
+class BatchedRunEnv(object):
+    def __init__(self, parameters_folder, game_level, global_batch, rank=0, world_size=1, device=None,
+                 config_overrides=None, thermal_limits=None, _lib_path=None, _lib_prefix='ppn_', **rule_kw):
+        level = os.path.join(parameters_folder, game_level)
+        grid = os.path.join(level, 'reference_grid.py')
+        if not os.path.exists(grid):
+            grid = os.path.join(level, 'reference_grid.json')
+        self.case = Case.from_file(grid)
+        with open(os.path.join(level, 'configuration.yaml')) as f:
+            self.conf = yaml.safe_load(f)
+        if config_overrides:
+            self.conf.update(config_overrides)
+        cdir = os.path.join(level, 'chronics')
+        self.chronics = [Chronic(os.path.join(cdir, c)) for c in sorted(os.listdir(cdir))
+                         if os.path.isdir(os.path.join(cdir, c)) or c.endswith('.npz')]
+        self.rank, self.world_size, self.global_batch = rank, world_size, global_batch
+        self.first, self.last = shard_range(global_batch, rank, world_size)
+        self.batch = self.last - self.first
+        self.env_ids = np.arange(self.first, self.last)
+        self.engine = Engine(self.case, self.conf, self.batch, device=rank if device is None else device,
+                             chronics=self.chronics, thermal_limits=thermal_limits, _lib_path=_lib_path,
+                             _lib_prefix=_lib_prefix, **rule_kw)
+        self.action_length = self.case.action_length
+        self.observation_length = self.case.observation_length
+
+    def reset(self):
+        slots, t0 = default_assignment(self.env_ids, self.chronics)
+        self.engine.reset(chronic_slot=slots, t0=t0)
+        return self.engine.observations()
+
+    def step(self, actions, auto_reset=True, want_obs=True):
+        """actions: uint8 [batch x action_length] of THIS shard.  Returns (obs|None, done, flag, illegal)."""
+        self.engine.step(actions, auto_reset=auto_reset)
+        done, flag, ill = self.engine.read('DONE'), self.engine.read('FLAG'), self.engine.read('ILLEGAL')
+        return (self.engine.observations() if want_obs else None), done.astype(bool), flag, ill
+
+    def simulate(self, actions):
+        self.engine.simulate(actions)
+        e = self.engine
+        return e.observations(simulation=True), e.read('DONE', simulation=True).astype(bool), \
+            e.read('FLAG', simulation=True), e.read('ILLEGAL', simulation=True)
+
+    # ---- single-controller helpers (the only collectives of the design) ---------------------------------------
+    def gather_to_root(self, array, root=0):
+        """Gather a per-environment array of every shard on `root` (variable shard sizes are padded)."""
+        import torch
+        import torch.distributed as dist
+        if self.world_size == 1:
+            return np.asarray(array)
+        a = np.ascontiguousarray(array)
+        sizes = [shard_range(self.global_batch, r, self.world_size) for r in range(self.world_size)]
+        mx = max(b - a_ for a_, b in sizes)
+        pad = np.zeros((mx,) + a.shape[1:], dtype=a.dtype)
+        pad[:a.shape[0]] = a
+        t = torch.from_numpy(pad)
+        if dist.get_backend() == 'nccl':
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(self.world_size)] if self.rank == root else None
+        dist.gather(t, out, dst=root)
+        if self.rank != root:
+            return None
+        return np.concatenate([o.cpu().numpy()[:b - a_] for o, (a_, b) in zip(out, sizes)])
+
+    def all_reduce_stats(self, values):
+        import torch
+        import torch.distributed as dist
+        if self.world_size == 1:
+            return np.asarray(values, dtype=np.float64)
+        t = torch.tensor(np.asarray(values, dtype=np.float64))
+        if dist.get_backend() == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()

@@ -1,0 +1,107 @@
+"""RunEnv drop-in API exercised end to end on the CPU emulation build (the same Python classes drive the GPU
+library).  Scenarios follow the reference's own tests: obs array <-> object round trip (tests/test_core.py:44-85,
+1430-1459, K11), simulate() leaves no trace (tests/test_simulate.py:371-536, K10), illegal-action payloads,
+WrappedRunner protocol."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, ENVS, oracle_game, do_nothing
+from oracle.game_np import obs_as_array
+from test_emu_engine import emu_lib  # noqa: F401  (fixture)
+
+
+def make_env(emu_lib, name, **kw):
+    from pypownet_amd.environment import RunEnv
+    return RunEnv(os.path.join(ENVS, name), 'level0', _lib_path=emu_lib, **kw)
+
+
+def test_obs_roundtrip_and_oracle_match(emu_lib):
+    env = make_env(emu_lib, 'default14_for_tests')
+    g = oracle_game('default14_for_tests')
+    arr = env.get_observation()
+    assert arr.shape == (env.game.case.observation_length,) == (538,)
+    obs = env.observation_space.array_to_observation(arr)
+    assert np.array_equal(obs.as_array(), arr)
+    np.testing.assert_allclose(arr, obs_as_array(g.export_observation()), rtol=0, atol=1e-6)
+    assert len(obs.as_minimalist().as_array()) + 0 < len(obs.as_ac_minimalist().as_array()) < len(arr)
+    conf, types = obs.get_nodes_of_substation(2)
+    assert list(conf) == [0] * 6 and len(types) == 6
+    st, other = obs.get_lines_status_of_substation(1)
+    assert list(st) == [1, 1] and other == [2, 5]
+
+
+def test_step_returns_reference_tuple_and_illegal_payload(emu_lib):
+    from pypownet_amd.environment import IllegalActionException
+    env = make_env(emu_lib, 'default14_for_tests')
+    a = env.action_space.get_do_nothing_action(as_class_Action=True)
+    env.action_space.set_lines_status_switch_from_id(a, 18, 1)
+    obs, reward, done, flag = env.step(a)
+    assert flag is None and not done and isinstance(reward, float)
+    o = env.observation_space.array_to_observation(obs)
+    assert int(o.lines_status[18]) == 0 and int(o.timesteps_before_lines_reactionable[18]) == 2
+    # switching it back immediately is on cooldown -> IllegalActionException returned (not raised), line stays off
+    a = env.action_space.get_do_nothing_action(as_class_Action=True)
+    env.action_space.set_lines_status_switch_from_id(a, 18, 1)
+    obs, rew_list, done, flag = env.step(a, do_sum=False)
+    assert isinstance(flag, IllegalActionException) and not done and len(rew_list) == 1
+    assert flag.get_illegal_oncoolown_lines_switches()[18] and flag.get_illegal_broken_lines_reconnections() is None
+    assert int(env.observation_space.array_to_observation(obs).lines_status[18]) == 0
+    # too many activations (max 2 lines in this env) -> whole action dropped
+    a = env.action_space.get_do_nothing_action(as_class_Action=True)
+    for k in (1, 2, 3):
+        env.action_space.set_lines_status_switch_from_id(a, k, 1)
+    assert not env.is_action_valid(a)
+    obs, r, done, flag = env.step(a)
+    assert isinstance(flag, IllegalActionException) and flag.get_has_too_much_activations()
+    assert list(env.observation_space.array_to_observation(obs).lines_status[:4].astype(int)) == [1, 1, 1, 1]
+    with pytest.raises(ValueError):
+        env.step(np.zeros(5))
+
+
+def test_simulate_leaves_no_trace(emu_lib):
+    env = make_env(emu_lib, 'default14_for_tests')
+    ref = make_env(emu_lib, 'default14_for_tests')
+    dn = env.action_space.get_do_nothing_action()
+    for t in range(6):
+        cand = env.action_space.get_do_nothing_action(as_class_Action=True)
+        env.action_space.set_lines_status_switch_from_id(cand, (3 * t) % 20, 1)
+        before = env.get_observation()
+        sobs, srew, sdone, sflag = env.simulate(cand)
+        assert np.array_equal(before, env.get_observation())          # nothing moved
+        if sobs is not None:
+            so = env.observation_space.array_to_observation(sobs)
+            # simulate plays the PLANNED injections of the current entry (game.py:415-419)
+            cur = env.observation_space.array_to_observation(before)
+            assert np.array_equal(so.active_loads, cur.planned_active_loads)
+        o1 = env.step(dn)
+        o2 = ref.step(dn)
+        assert np.array_equal(o1[0], o2[0]) and o1[1] == o2[1]
+
+
+def test_game_over_and_process_game_over(emu_lib):
+    from pypownet_amd.environment import TooManyProductionsCut
+    env = make_env(emu_lib, 'default14_for_tests')
+    env.process_game_over()
+    a = env.action_space.get_do_nothing_action(as_class_Action=True)
+    a.prods_switches_subaction[0] = 1
+    obs, r, done, flag = env.step(a)
+    assert not done
+    a = env.action_space.get_do_nothing_action(as_class_Action=True)
+    a.prods_switches_subaction[4] = 1
+    obs, r, done, flag = env.step(a)
+    assert done and obs is None and isinstance(flag, TooManyProductionsCut)
+    arr = env.process_game_over()
+    o = env.observation_space.array_to_observation(arr)
+    assert list(o.productions_nodes.astype(int)) == [0] * 5
+
+
+def test_default_reward_signal(emu_lib):
+    from pypownet_amd.reward_signal import DefaultGridRewardSignal
+    env = make_env(emu_lib, 'default14_for_tests')
+    env.reward_signal = DefaultGridRewardSignal(14)
+    obs, r, done, flag = env.step(env.action_space.get_do_nothing_action(), do_sum=False)
+    assert len(r) == 5 and r[0] == 0 and r[1] == 0 and r[2] == 0 and r[3] == 0 and r[4] < 0
+    o = env.observation_space.array_to_observation(obs)
+    assert abs(r[4] + np.sum(np.square(o.ampere_flows / o.thermal_limits))) < 1e-12
