@@ -120,7 +120,8 @@ def main():
     case, conf, chronics = load_workload()
     limits = bench_limits(case)
     B = args.batch
-    eng = Engine(case, conf, B, device=local_rank, chronics=chronics, thermal_limits=limits, max_active_buses=128)
+    eng = Engine(case, conf, B, device=local_rank, chronics=chronics, thermal_limits=limits, max_active_buses=case.nS,
+                 lu_capacity=int(os.environ.get('PPN_BENCH_LU_CAPACITY', '0')))   # (occupancy experiments only)
     slots, t0 = env_assignment(rank * B, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
     actions = torch.zeros((B, case.action_length), dtype=torch.uint8, device='cuda:%d' % local_rank)

@@ -22,13 +22,25 @@ typedef unsigned char u8;
 #define PPN_DEV static inline
 #define LANE_LOOP for (int lane = 0; lane < 64; ++lane)
 #define WSYNC() ((void)0)
+#define WSYNC_G() ((void)0)
+// per-lane variables that live across LANE_LOOP regions (registers on the GPU)
+#define LANE_VAR(type, name) type name[64]
+#define LANE_ARR(type, name, n) type name[64][n]
+#define LV(name) name[lane]
 #define PPN_UNI(x) (x)
 static inline int ppn_popc(u64 x) { return __builtin_popcountll(x); }
 static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #else
 #define PPN_DEV __device__ __forceinline__
 #define LANE_LOOP for (int lane = lane0, once_ = 1; once_; once_ = 0)
-#define WSYNC() __syncthreads()
+// One wavefront per workgroup: LDS operations of a wave execute in order, so ordering LDS phases only needs the
+// compiler not to move memory accesses across the point (and pending LDS results to have landed).  Global loads
+// may stay in flight across WSYNC (prefetched schedule records); WSYNC_G also orders global memory.
+#define WSYNC() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WSYNC_G() __syncthreads()
+#define LANE_VAR(type, name) type name
+#define LANE_ARR(type, name, n) type name[n]
+#define LV(name) name
 #define PPN_UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ int ppn_popc(u64 x) { return __popcll(x); }
 __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
@@ -73,7 +85,7 @@ struct DevRules {
 // Static (shared by all environments) + chronic tensors.  All pointers are device pointers.
 struct DevCase {
   int nS, nP, nL, nl, nrows, ntopo, alen, obslen;
-  int NB, YCAP, LUCAP;     // LDS capacities: active buses, Ybus entries, LU doubles
+  int NB, YCAP, LUCAP, ECAP;   // capacities: active buses, Ybus entries, LU doubles (= 4*ECAP), filled pattern entries
   double baseMVA;
   const double *bus_gs, *bus_bs, *bus_kv, *vm0, *va0;   // [nrows]  (va0 degrees)
   const int *gen_sub, *load_sub, *or_sub, *ex_sub;       // substation index of each element
@@ -114,21 +126,26 @@ struct DevState {
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
   long long* prof;                 // [16] cycle counters per phase (only written by -DPPN_PROF builds)
+  // per-environment solve workspace (L2-resident, streamed sequentially by the numeric phases)
+  u64 *ws_tri, *ws_pair;           // [TCAP], [MCAP] update triples / (pivot, neighbour) pairs with entry indices
+  unsigned *ws_piv;                // [NB] pivots (diagonal entry | k << 16)
 };
 
-// LDS carve-up (pointers into the workgroup's dynamic shared memory)
+// LDS carve-up (pointers into the workgroup's dynamic shared memory).  The arrays of the "setup" group are only
+// alive while a solve is being prepared (pattern, schedule) or outside a solve (action decoding, ampere flows) and
+// are overlaid on the matrix storage `lu`, which is dead at those times.
 struct Smem {
+  // persistent during a solve
+  double *lu;
+  double *vm, *va, *vr, *vi, *psp, *qsp, *mr, *mi, *rhs;
+  u16 *rowptr, *row2int, *int2row, *lvlp, *lvlm, *lvlt, *ediag, *le4;
+  u8 *nv, *touched, *hasgen, *genon, *st, *on, *en, *pn, *ln, *lf, *lt, *over;
+  // setup group (aliases lu)
   u64 *adj0, *adjF;
-  double *yre, *yim, *lu;
-  double *vm, *va, *vr, *vi, *psp, *qsp, *mr, *mi, *rhs, *gvg, *pinj;
-  double *amps;
-  u16 *yptr, *luoff, *luoff2, *row2int, *int2row, *slist, *scn;
-  u8 *nv, *nv2, *touched, *hasgen, *genon;
-  u8 *st, *on, *en, *pn, *ln, *subchg, *act, *over;
-  int *red;
-  // per-solve elimination schedule
-  u8 *pvl, *kq, *mem, *mown, *tri, *ycol, *yrow;
-  u16 *moffq, *toffq, *lvlp, *lvlm, *lvlt, *jpos;
+  double *yre, *yim, *gvg, *amps;
+  u16 *yptr, *scn, *moffq, *toffq;
+  unsigned *ymeta;
+  u8 *pvl, *kq, *mem, *mown, *subchg, *act;
 };
 
 #ifdef PPN_EMU
@@ -144,24 +161,28 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) 
   size_t o = 0;
   const size_t NB = d.NB, nl = d.nl, nrows = d.nrows;
 #define PPN_TAKE(field, type, bytes) S.field = (type*)(base + o); o += (((size_t)(bytes)) + 15) & ~(size_t)15;
+  // setup group first (overlaid on lu)
   PPN_TAKE(adj0, u64, NB * W * 8) PPN_TAKE(adjF, u64, NB * W * 8)
   PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8)
-  PPN_TAKE(lu, double, (size_t)d.LUCAP * 8)
-  PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(vr, double, NB * 8) PPN_TAKE(vi, double, NB * 8)
-  PPN_TAKE(psp, double, NB * 8) PPN_TAKE(qsp, double, NB * 8) PPN_TAKE(mr, double, NB * 8) PPN_TAKE(mi, double, NB * 8)
-  PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(pinj, double, NB * 8)
-  PPN_TAKE(amps, double, nl * 8)
-  PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(luoff, u16, (NB + 1) * 2) PPN_TAKE(luoff2, u16, (NB + 1) * 2)
-  PPN_TAKE(row2int, u16, nrows * 2) PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(slist, u16, 64 * 2)
-  PPN_TAKE(scn, u16, (nrows + 1) * 2)
-  PPN_TAKE(nv, u8, NB) PPN_TAKE(nv2, u8, NB) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
-  PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
-  PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen) PPN_TAKE(over, u8, nl) PPN_TAKE(red, int, 64 * 4)
-  PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
-  PPN_TAKE(tri, u8, 3 * (size_t)d.TCAP) PPN_TAKE(ycol, u8, (size_t)d.YCAP) PPN_TAKE(yrow, u8, (size_t)d.YCAP)
+  PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(amps, double, nl * 8) PPN_TAKE(ymeta, unsigned, (size_t)d.YCAP * 4)
+  PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(scn, u16, (nrows + 1) * 2)
   PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)
+  PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
+  PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
+  const size_t setup_bytes = o;
+  const size_t lu_bytes = (size_t)d.LUCAP * 8;
+  S.lu = (double*)base;
+  o = (setup_bytes > lu_bytes ? setup_bytes : lu_bytes);
+  o = (o + 15) & ~(size_t)15;
+  PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(vr, double, NB * 8) PPN_TAKE(vi, double, NB * 8)
+  PPN_TAKE(psp, double, NB * 8) PPN_TAKE(qsp, double, NB * 8)
+  PPN_TAKE(mr, double, NB * 8) PPN_TAKE(mi, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8)
+  PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(row2int, u16, nrows * 2) PPN_TAKE(int2row, u16, NB * 2)
   PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
-  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(jpos, u16, (size_t)d.YCAP * 2)
+  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(ediag, u16, NB * 2) PPN_TAKE(le4, u16, nl * 4 * 2)
+  PPN_TAKE(nv, u8, NB) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
+  PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
+  PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl) PPN_TAKE(over, u8, nl)
 #undef PPN_TAKE
   return o;
 }

@@ -126,7 +126,7 @@ struct KArgs {
   u8* valid;
   const int *ids, *slots, *t0;
   double* obs;
-  int sim;
+  int sim, auto_reset;
 };
 
 #ifndef PPN_EMU
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64) ppn_kernel(const KArgs a) {
   ppn_carve(a.d, W, smem, &S);
   const int env = blockIdx.x;
   const int lane0 = threadIdx.x;
-  if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, env, lane0);
+  if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, lane0);
   else if (KIND == K_GAMEOVER) body_game_over<W>(a.d, a.st, S, a.valid, env, lane0);
   else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, lane0);
   else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, lane0);
@@ -156,7 +156,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   ppn_carve(a.d, W, base, &S);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, 0xA5, e->lds_bytes);   // LDS is NOT zero-initialised on the GPU either
-    if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, env, 0);
+    if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, 0);
     else if (KIND == K_GAMEOVER) body_game_over<W>(a.d, a.st, S, a.valid, env, 0);
     else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, 0);
@@ -285,7 +285,9 @@ static int alloc_state(ppn_engine* e, DevState* s) {
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
   s->prof = dalloc<long long>(e, B * 16);
-  return s->prof ? 0 : -1;
+  s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
+  s->ws_piv = dalloc<unsigned>(e, B * d.NB);
+  return s->ws_piv ? 0 : -1;
 }
 
 struct FieldInfo { size_t elem; int n; size_t off; };   // off: byte offset of the pointer inside DevState
@@ -505,23 +507,27 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.NB = NB;
   e->W = (NB + 63) / 64;
   d.YCAP = NB + 2 * nl;
-  if (d.YCAP > 65000) d.YCAP = 65000;
+  {
+    const int ypl = (e->W == 1) ? 4 : (e->W == 2 ? 8 : (e->W == 3 ? 10 : 12));   // Ybus entries held per lane (registers)
+    if (d.YCAP > 64 * ypl) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "Ybus of this case (%d entries) exceeds the register budget of the W=%d kernel", d.YCAP, e->W); }
+  }
   d.nlev = nlev;
   {
-    const double grow = (NB > nS) ? 3.0 : 1.5;   // node splitting adds busbars and fill
+    const double grow = 1.3 + 1.7 * ((NB > nS) ? (double)(NB - nS) / nS : 0.0);   // node splitting adds busbars and fill
     d.MCAP = ((int)(base_pairs * grow) + 64 + 15) & ~15;
     d.TCAP = ((int)(base_tri * grow) + 256 + 15) & ~15;
     if (d.MCAP > 65000 || d.TCAP > 21000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "schedule capacity exceeds 16-bit offsets"); }
   }
-  int lucap = r->lu_capacity;
-  if (lucap <= 0) {
-    lucap = (int)(e->base_fill * 1.30) + 192;
-    if (NB > nS) lucap = (int)(lucap * 1.6);
-    const int fd_need = 2 * pairs + 64;        // B' + B'' storages of the fast-decoupled solver
-    if (lucap < fd_need) lucap = fd_need;
+  // filled-pattern capacity (entries); the LU storage holds 2x2 blocks: LUCAP = 4 * ECAP doubles
+  int ecap = r->lu_capacity > 0 ? (r->lu_capacity + 3) / 4 : 0;
+  if (ecap <= 0) {
+    const double extra = (NB > nS) ? (double)(NB - nS) / nS : 0.0;   // share of busbars that may be split off
+    // line cuts never add fill: without spare busbars the base fill is exact
+    ecap = (NB > nS) ? (int)(pairs * (1.10 + 2.0 * extra)) + 16 : pairs;
   }
-  d.LUCAP = (lucap + 7) & ~7;
-  if (d.LUCAP > 65000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds 16-bit offsets"); }
+  d.ECAP = (ecap + 7) & ~7;
+  d.LUCAP = 4 * d.ECAP;
+  if (d.ECAP > 16000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds 16-bit entry indices"); }
   { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); }
   if (e->lds_bytes > 160 * 1024) {
     free_all(e); delete e;
@@ -708,11 +714,8 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
   }
   if (simulate) { if (copy_state(e, &e->sim, &e->st)) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err()); }
   KArgs a = make_args(e, simulate != 0);
-  a.actions = dact; a.sim = simulate ? 1 : 0;
+  a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = (auto_reset && !simulate) ? 1 : 0;
   if (launch<K_STEP>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
-  if (auto_reset && !simulate) {
-    if (launch<K_GAMEOVER>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "game-over kernel launch failed: %s", dev_err());
-  }
   return PPN_OK;
 }
 

@@ -155,3 +155,46 @@ def check_topology_scenarios(lib_path, env, nodes, n_iter, policy_factory, solve
             eng.process_game_over()
         compare_state(eng, games)
     return flags_seen
+
+
+def check_auto_reset_and_cascade_118(lib_path, steps=25, batch=6, solver='newton'):
+    """default118 with the benchmark's synthetic limits (cascades + game overs happen): (a) auto_reset fused in the
+    step == step followed by process_game_over, (b) lock-step equality with the C oracle (flags, line status,
+    counters exact; voltages 1e-8)."""
+    import json
+    import os
+    from helpers import ENVS, ROOT
+    from pypownet_amd.engine import Engine
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env('default118', conf={'solver': solver})
+    with open(os.path.join(ENVS, 'default118', 'bench_limits.json')) as f:
+        limits = np.asarray(json.load(f)['limits_a'])
+    prefix = 'orc_' if (lib_path and 'liboracle' in lib_path) else 'ppn_'
+    mk = lambda lp, pf: Engine(case, cfg, batch, chronics=chronics, thermal_limits=limits, _lib_path=lp, _lib_prefix=pf)
+    a, b = mk(lib_path, prefix), mk(lib_path, prefix)
+    orc = mk(os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'), 'orc_')
+    slots, t0 = default_assignment(np.arange(batch) * 5, chronics)
+    for e in (a, b, orc):
+        e.reset(chronic_slot=slots, t0=t0)
+    act = np.zeros((batch, case.action_length), dtype=np.uint8)
+    n_done = 0
+    for t in range(steps):
+        a.step(act, auto_reset=True)
+        b.step(act)
+        orc.step(act, auto_reset=True)
+        done = b.read('DONE')
+        n_done += int(done.sum())
+        assert np.array_equal(a.read('DONE'), done) and np.array_equal(a.read('FLAG'), b.read('FLAG'))
+        assert np.array_equal(orc.read('DONE'), done) and np.array_equal(orc.read('FLAG'), b.read('FLAG'))
+        assert np.array_equal(orc.read('CASCADE_DEPTH'), a.read('CASCADE_DEPTH'))
+        b.process_game_over()
+        for f in ('LINES_STATUS', 'RECONNECTABLE', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES'):
+            assert np.array_equal(a.read(f), b.read(f)), f
+            assert np.array_equal(a.read(f), orc.read(f)), f
+        for f in ('VM', 'VA', 'PF', 'AMPS'):
+            assert np.array_equal(a.read(f), b.read(f)), f
+        bt = orc.read('BUS_TYPE')
+        act_rows = bt != 4
+        np.testing.assert_allclose(a.read('VM')[act_rows], orc.read('VM')[act_rows], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(a.read('AMPS'), orc.read('AMPS'), rtol=0, atol=1e-5)
+    return n_done

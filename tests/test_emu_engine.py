@@ -62,3 +62,9 @@ def test_emu_k3_dc(emu_lib):
 
 def test_emu_default118_few_steps(emu_lib):
     ec.check_do_nothing(emu_lib, 'default118', 'newton', steps=3, batch=1)
+
+
+def test_emu_auto_reset_and_cascade_118(emu_lib):
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
+    assert ec.check_auto_reset_and_cascade_118(emu_lib, steps=20, batch=4) > 0

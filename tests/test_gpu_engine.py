@@ -47,3 +47,8 @@ def test_gpu_k3_dc():
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_gpu_default118_steps(solver):
     ec.check_do_nothing(HIP, 'default118', solver, steps=6, batch=3)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_auto_reset_and_cascade_118(solver):
+    assert ec.check_auto_reset_and_cascade_118(HIP, steps=40, batch=64, solver=solver) > 0

@@ -13,7 +13,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 NAMES = ['A-C types/compaction', 'adjacency', 'symbolic', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
-         'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)']
+         'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)', 'LU: bounds+prefetch', 'LU: phase0',
+         'LU: phase1', 'LU: phase2']
 
 
 def main():
@@ -28,7 +29,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     case, conf, chronics = bench.load_workload()
-    eng = Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=128,
+    eng = Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS,
                  _lib_path=lib)
     slots, t0 = bench.env_assignment(0, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
@@ -47,8 +48,8 @@ def main():
     nsolve, nit = float(s1 - s0), float(i1 - i0)
     print('B=%d steps=%d solves=%d iterations=%d' % (B, steps, nsolve, nit))
     for k, name in enumerate(NAMES):
-        per = tot[k] / (nit if k in (4, 5, 6) else nsolve)
-        print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, 'iteration' if k in (4, 5, 6) else 'solve'))
+        per = tot[k] / (nit if k in (4, 5, 6, 11, 12, 13, 14) else nsolve)
+        print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, 'iteration' if k in (4, 5, 6, 11, 12, 13, 14) else 'solve'))
 
 
 if __name__ == '__main__':
