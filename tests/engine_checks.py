@@ -198,3 +198,63 @@ def check_auto_reset_and_cascade_118(lib_path, steps=25, batch=6, solver='newton
         np.testing.assert_allclose(a.read('VM')[act_rows], orc.read('VM')[act_rows], rtol=0, atol=1e-8)
         np.testing.assert_allclose(a.read('AMPS'), orc.read('AMPS'), rtol=0, atol=1e-5)
     return n_done
+
+
+def random_actions(case, rng, batch, p_node=0.6, p_line=0.3):
+    """RandomNodeSplitting-style actions (reference pypownet/agent.py:116-158): per environment one random
+    substation gets a random configuration of switches; with probability p_line a random line switch is added."""
+    acts = np.zeros((batch, case.action_length), dtype=np.uint8)
+    for b in range(batch):
+        if rng.random() < p_node:
+            s = int(rng.integers(case.nS))
+            idx = np.asarray(case.mapping_array[s], dtype=int)
+            acts[b, idx] = rng.integers(0, 2, size=len(idx))
+        if rng.random() < p_line:
+            acts[b, case.ntopo_offset_lines + int(rng.integers(case.nl))] = 1
+    return acts
+
+
+def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='newton', seed=1234, conf=None):
+    """Lock-step with the C oracle under random node-splitting / line-switching actions (dynamic Ybus rebuild every
+    step, illegal-action repair, cooldowns, islanding, game overs + auto reset): flags, topology, counters bit-exact,
+    voltages <= 1e-8 on live environments."""
+    import os
+    from helpers import ROOT
+    from pypownet_amd.engine import Engine
+    cf = {'solver': solver}
+    if conf:
+        cf.update(conf)
+    case, cfg, chronics = load_env(envname, conf=cf)
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    prefix = 'orc_' if (lib_path and 'liboracle' in lib_path) else 'ppn_'
+    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, _lib_prefix=prefix)
+    orc = Engine(case, cfg, batch, chronics=chronics, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
+                 _lib_prefix='orc_')
+    rng = np.random.default_rng(seed)
+    eng.reset()
+    orc.reset()
+    stats = dict(done=0, illegal=0, split_buses=0)
+    for t in range(steps):
+        acts = random_actions(case, rng, batch)
+        ve, vo = eng.is_action_valid(acts), orc.is_action_valid(acts)
+        assert np.array_equal(ve, vo), 'is_action_valid differs at step %d' % t
+        eng.step(acts, auto_reset=True)
+        orc.step(acts, auto_reset=True)
+        for f in ('DONE', 'FLAG', 'ILLEGAL', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES',
+                  'LINES_EX_NODES', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN', 'SOFT_COUNT', 'CHRONIC_ROW',
+                  'CHRONIC_SLOT', 'N_LOADS_CUT', 'N_PRODS_CUT', 'CASCADE_DEPTH', 'N_SOLVES'):
+            a, b = eng.read(f), orc.read(f)
+            assert np.array_equal(a, b), '%s differs at step %d (envs %s)' % (
+                f, t, np.where((a != b).reshape(batch, -1).any(axis=1))[0][:8])
+        assert int((eng.read('FLAG') == 4).sum()) == 0, 'engine capacity error'
+        bt = orc.read('BUS_TYPE')
+        live = bt != 4
+        assert np.array_equal(eng.read('BUS_TYPE') != 4, live)
+        np.testing.assert_allclose(eng.read('VM')[live], orc.read('VM')[live], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(np.deg2rad(eng.read('VA')[live]), np.deg2rad(orc.read('VA')[live]), rtol=0, atol=1e-8)
+        np.testing.assert_allclose(eng.read('AMPS'), orc.read('AMPS'), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(eng.read('QG'), orc.read('QG'), rtol=0, atol=1e-5)
+        stats['done'] += int(orc.read('DONE').sum())
+        stats['illegal'] += int((orc.read('ILLEGAL') != 0).sum())
+        stats['split_buses'] = max(stats['split_buses'], int((bt[:, case.nS:] != 4).sum(axis=1).max()))
+    return stats

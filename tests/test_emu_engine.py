@@ -68,3 +68,14 @@ def test_emu_auto_reset_and_cascade_118(emu_lib):
     import subprocess
     subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
     assert ec.check_auto_reset_and_cascade_118(emu_lib, steps=20, batch=4) > 0
+
+
+@pytest.mark.parametrize('env,solver,steps,batch', [('default14_for_tests_alpha', 'newton', 40, 6),
+                                                     ('default14_for_tests_alpha', 'fdxb', 40, 6),
+                                                     ('default14_for_tests_beta', 'fdxb', 30, 4),
+                                                     ('default118', 'newton', 12, 3)])
+def test_emu_random_actions_vs_c_oracle(emu_lib, env, solver, steps, batch):
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
+    st = ec.check_random_actions_vs_c_oracle(emu_lib, env, steps, batch, solver)
+    assert st['split_buses'] > 0

@@ -52,3 +52,15 @@ def test_gpu_default118_steps(solver):
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_gpu_auto_reset_and_cascade_118(solver):
     assert ec.check_auto_reset_and_cascade_118(HIP, steps=40, batch=64, solver=solver) > 0
+
+
+@pytest.mark.parametrize('env,solver,steps,batch', [('default14_for_tests_alpha', 'newton', 60, 64),
+                                                     ('default14_for_tests_alpha', 'fdxb', 60, 64),
+                                                     ('default14_for_tests_beta', 'fdxb', 40, 32),
+                                                     ('default118', 'newton', 40, 96),
+                                                     ('default118', 'fdxb', 25, 64)])
+def test_gpu_random_actions_vs_c_oracle(env, solver, steps, batch):
+    """BASELINE.json configs[4] semantics (per-env random node splitting => dynamic Ybus rebuild) at parity size; the
+    full-capacity (every busbar may be active) W=4 kernels are the ones exercised on default118."""
+    st = ec.check_random_actions_vs_c_oracle(HIP, env, steps, batch, solver)
+    assert st['split_buses'] > 0 and st['illegal'] > 0
