@@ -65,7 +65,7 @@ __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #define LDS_OR(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
 #endif
 
-#define PPN_NONE 0xFFFFu
+#define PPN_NONE 0xFFu     // 'no internal index' in the u8 row -> bus table (max_active_buses <= 254)
 #define PPN_PI 3.14159265358979323846
 
 // solve outcomes (internal)
@@ -138,14 +138,15 @@ struct Smem {
   // persistent during a solve
   double *lu;
   double *vm, *va, *vr, *vi, *psp, *qsp, *mr, *mi, *rhs;
-  u16 *rowptr, *row2int, *int2row, *lvlp, *lvlm, *lvlt, *ediag, *le4;
-  u8 *nv, *touched, *hasgen, *genon, *st, *on, *en, *pn, *ln, *lf, *lt, *over;
+  u16 *int2row, *lvlp, *lvlm, *lvlt, *ediag;
+  u8 *row2int, *nv, *st, *on, *en, *pn, *ln, *lf, *lt;
+  u16 *le4;      // entry indices of the 4 blocks of every line: lives in the unused tail of lu (scalar solvers only)
   // setup group (aliases lu)
   u64 *adj0, *adjF;
   double *yre, *yim, *gvg, *amps;
-  u16 *yptr, *scn, *moffq, *toffq;
+  u16 *yptr, *scn, *moffq, *toffq, *rowptr;
   unsigned *ymeta;
-  u8 *pvl, *kq, *mem, *mown, *subchg, *act;
+  u8 *pvl, *kq, *mem, *mown, *subchg, *act, *touched, *hasgen, *genon, *over;
 };
 
 #ifdef PPN_EMU
@@ -164,11 +165,25 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) 
   // setup group first (overlaid on lu)
   PPN_TAKE(adj0, u64, NB * W * 8) PPN_TAKE(adjF, u64, NB * W * 8)
   PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8)
-  PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(amps, double, nl * 8) PPN_TAKE(ymeta, unsigned, (size_t)d.YCAP * 4)
+  PPN_TAKE(amps, double, nl * 8) PPN_TAKE(ymeta, unsigned, (size_t)d.YCAP * 4)
   PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(scn, u16, (nrows + 1) * 2)
   PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)
   PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
-  PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
+  PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
+  PPN_TAKE(over, u8, nl)
+  // le4 must survive into the scalar solvers (DC / fast-decoupled), whose matrices use at most 2*ECAP doubles; it is
+  // written while building the schedule, when gvg (phase C) and the decoded action are dead: it overlays them
+  {
+    const size_t scalar_lu = 2 * (size_t)d.ECAP * 8;
+    if (o < scalar_lu) o = (scalar_lu + 15) & ~(size_t)15;
+  }
+  S.le4 = (u16*)(base + o);
+  {
+    const size_t o0 = o;
+    PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
+    const size_t need = ((nl * 4 * 2) + 15) & ~(size_t)15;
+    if (o - o0 < need) o = o0 + need;
+  }
   const size_t setup_bytes = o;
   const size_t lu_bytes = (size_t)d.LUCAP * 8;
   S.lu = (double*)base;
@@ -177,12 +192,12 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) 
   PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(vr, double, NB * 8) PPN_TAKE(vi, double, NB * 8)
   PPN_TAKE(psp, double, NB * 8) PPN_TAKE(qsp, double, NB * 8)
   PPN_TAKE(mr, double, NB * 8) PPN_TAKE(mi, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8)
-  PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(row2int, u16, nrows * 2) PPN_TAKE(int2row, u16, NB * 2)
+  PPN_TAKE(int2row, u16, NB * 2)
   PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
-  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(ediag, u16, NB * 2) PPN_TAKE(le4, u16, nl * 4 * 2)
-  PPN_TAKE(nv, u8, NB) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
+  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(ediag, u16, NB * 2)
+  PPN_TAKE(row2int, u8, nrows) PPN_TAKE(nv, u8, NB)
   PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
-  PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl) PPN_TAKE(over, u8, nl)
+  PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl)
 #undef PPN_TAKE
   return o;
 }

@@ -66,6 +66,7 @@ struct ppn_engine {
   std::vector<void*> allocs;
   std::vector<HostChronic> chronics;
   bool chronics_dirty = true;
+  bool maybe_dead = true;     // some environment may be over at the next ppn_step (see ppn_step)
   std::vector<void*> chronic_allocs;
   hipStream_t stream = 0;
   size_t lds_bytes = 0;
@@ -522,7 +523,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.baseMVA = c->base_mva; d.slack_row = slack_row;
   int NB = r->max_active_buses > 0 ? std::min(r->max_active_buses, nrows) : nrows;
   if (NB < 2) NB = 2;
-  if (NB > 256) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "more than 256 active busbars are not supported"); }
+  if (NB > 254) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "more than 254 active busbars are not supported"); }
   d.NB = NB;
   e->W = (NB + 63) / 64;
   d.YCAP = NB + 2 * nl;
@@ -703,6 +704,7 @@ extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const
   KArgs a = make_args(e, false);
   a.ids = e->d_ids; a.slots = e->d_ids + e->batch; a.t0 = e->d_ids + 2 * e->batch;
   if (launch<K_RESET>(e, a, n)) return fail(e, PPN_E_HIP, "reset kernel launch failed: %s", dev_err());
+  e->maybe_dead = true;
   return PPN_OK;
 }
 
@@ -735,6 +737,14 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
   KArgs a = make_args(e, simulate != 0);
   a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = (auto_reset && !simulate) ? 1 : 0;
   if (launch<K_STEP>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  if (a.auto_reset && e->maybe_dead) {
+    // environments that were already over when the step began (after ppn_reset or after steps without auto_reset) did
+    // not step; they are restarted by this post-pass.  Environments that end DURING a step restart inside the step
+    // kernel, so from the second auto-reset step on nothing is left to do here.
+    if (launch<K_GAMEOVER>(e, a, e->batch)) return fail(e, PPN_E_HIP, "game-over kernel launch failed: %s", dev_err());
+    e->maybe_dead = false;
+  }
+  if (!a.auto_reset && !simulate) e->maybe_dead = true;
   return PPN_OK;
 }
 
