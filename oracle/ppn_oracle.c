@@ -70,6 +70,7 @@ typedef struct {
   uint8_t *pn, *ln, *on, *en, *st, *btype;
   int *rec, *lcd, *ncd, *soft;
   int done, dead, succ, flag, ill, depth, nsolve, niter, slot, row, nlc, npc, epoch;
+  double min_vm;    /* test diagnostic: smallest |V| of an active bus over the successful solves of the last step */
 } OEnv;
 
 struct orc_engine {
@@ -502,6 +503,7 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
     }
     free(V);
     rc = (success && !bad) ? 0 : 1;
+    if (success) for (int i = 0; i < n; ++i) if (vm[i] < e->min_vm) e->min_vm = vm[i];
   }
 done:
   free(touched); free(hasgen); free(genon); free(e2i); free(i2e); free(typ); free(perm);
@@ -637,6 +639,7 @@ static void orc_reset_grid(const OCase* c, OEnv* e) {
 }
 
 static void orc_step_env(const OCase* c, OEnv* e, const uint8_t* action, int sim) {
+  e->min_vm = 1e300;
   if (e->dead) return;
   const int ill = orc_apply_action(c, e, action, 1);
   orc_advance(c, e, sim);
@@ -886,6 +889,9 @@ int orc_write(orc_engine* E, ppn_field f, const void* src, size_t bytes) {
 }
 
 int orc_sync(orc_engine* E) { (void)E; return PPN_OK; }
+/* oracle-only diagnostic (tests): smallest |V| of an active bus over the successful solves of each environment's last step
+ * (before any game-over restart); lets the lock-step tests set aside voltage-collapse cases, which are rounding luck. */
+int orc_debug_min_vm(orc_engine* E, double* out) { for (int k = 0; k < E->batch; ++k) out[k] = E->env[k].min_vm; return PPN_OK; }
 void* orc_stream(orc_engine* E) { (void)E; return NULL; }
 int orc_kernel_time(orc_engine* E, int32_t reset, double* ms, int64_t* n) { (void)E; (void)reset; if (ms) *ms = 0; if (n) *n = 0; return PPN_OK; }
 int32_t orc_dim(const orc_engine* E, int32_t which) {

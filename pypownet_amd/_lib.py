@@ -73,7 +73,7 @@ class _Prefixed(object):
 
 
 def load_library(path=None, prefix='ppn_'):
-    path = path or LIB_PATH
+    path = path or os.environ.get('PPN_LIB') or LIB_PATH   # PPN_LIB: experimental builds of the same library
     if not os.path.exists(path):
         raise ImportError(
             'pypownet_amd: the HIP extension %s is missing. Build it with `python __graft_entry__.py` '

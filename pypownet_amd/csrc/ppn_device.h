@@ -17,6 +17,7 @@
 typedef unsigned long long u64;
 typedef unsigned short u16;
 typedef unsigned char u8;
+struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LDS access
 
 #ifdef PPN_EMU
 #define PPN_DEV static inline
@@ -27,6 +28,7 @@ typedef unsigned char u8;
 #define LANE_VAR(type, name) type name[64]
 #define LANE_ARR(type, name, n) type name[64][n]
 #define LV(name) name[lane]
+#define LANE_READ(v, l) ((v)[(l)])          // value held by lane l (l wave-uniform)
 #define PPN_UNI(x) (x)
 static inline int ppn_popc(u64 x) { return __builtin_popcountll(x); }
 static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
@@ -41,6 +43,7 @@ static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #define LANE_VAR(type, name) type name
 #define LANE_ARR(type, name, n) type name[n]
 #define LV(name) name
+#define LANE_READ(v, l) ((unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
 #define PPN_UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ int ppn_popc(u64 x) { return __popcll(x); }
 __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
@@ -50,9 +53,13 @@ __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #if defined(PPN_PROF) && !defined(PPN_EMU)
 #define PROF_BEGIN() long long t_prof_ = clock64()
 #define PROF_MARK(E_, id) do { const long long t2_ = clock64(); if (lane0 == 0) (E_).prof[id] += t2_ - t_prof_; t_prof_ = clock64(); } while (0)
+#define PROF_BODY_BEGIN() const long long pb_c_ = clock64(), pb_w_ = wall_clock64()
+#define PROF_BODY_END(E_) do { if (lane0 == 0) { (E_).prof[14] += clock64() - pb_c_; (E_).prof[15] += wall_clock64() - pb_w_; } } while (0)
 #else
 #define PROF_BEGIN() ((void)0)
 #define PROF_MARK(E_, id) ((void)0)
+#define PROF_BODY_BEGIN() ((void)0)
+#define PROF_BODY_END(E_) ((void)0)
 #endif
 
 // LDS atomics (one wave per workgroup: conflicting lanes are serialised by the LDS unit in a fixed order, so
@@ -137,7 +144,7 @@ struct DevState {
 struct Smem {
   // persistent during a solve
   double *lu;
-  double *vm, *va, *vr, *vi, *psp, *qsp, *mr, *mi, *rhs;
+  double *vm, *va, *vc, *ivm, *psp, *qsp, *mr, *mi, *rhs;   // vc: V = vc[2i] + j vc[2i+1]; ivm: 1 / |V_i|
   u16 *int2row, *lvlp, *lvlm, *lvlt, *ediag;
   u8 *row2int, *nv, *st, *on, *en, *pn, *ln, *lf, *lt;
   u16 *le4;      // entry indices of the 4 blocks of every line: lives in the unused tail of lu (scalar solvers only)
@@ -189,7 +196,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) 
   S.lu = (double*)base;
   o = (setup_bytes > lu_bytes ? setup_bytes : lu_bytes);
   o = (o + 15) & ~(size_t)15;
-  PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(vr, double, NB * 8) PPN_TAKE(vi, double, NB * 8)
+  PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(ivm, double, NB * 8)
   PPN_TAKE(psp, double, NB * 8) PPN_TAKE(qsp, double, NB * 8)
   PPN_TAKE(mr, double, NB * 8) PPN_TAKE(mi, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8)
   PPN_TAKE(int2row, u16, NB * 2)

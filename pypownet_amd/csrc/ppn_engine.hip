@@ -132,7 +132,10 @@ struct KArgs {
 
 #ifndef PPN_EMU
 template <int W, int KIND>
-__global__ void __launch_bounds__(64) ppn_kernel(const KArgs a) {
+#ifndef PPN_WAVES_PER_EU
+#define PPN_WAVES_PER_EU 1
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPN_WAVES_PER_EU))) ppn_kernel(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Smem S;
   ppn_carve(a.d, W, smem, &S);
@@ -532,6 +535,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     if (d.YCAP > 64 * ypl) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "Ybus of this case (%d entries) exceeds the register budget of the W=%d kernel", d.YCAP, e->W); }
   }
   d.nlev = nlev;
+  if (nlev + 1 > 128) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "elimination forest deeper than 63 substation levels"); }
   {
     const double grow = 1.3 + 1.7 * ((NB > nS) ? (double)(NB - nS) / nS : 0.0);   // node splitting adds busbars and fill
     d.MCAP = ((int)(base_pairs * grow) + 64 + 15) & ~15;

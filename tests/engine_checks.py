@@ -1,4 +1,6 @@
 """Engine-vs-oracle checks shared by the CPU emulation tests and the GPU parity tests."""
+import ctypes as C
+
 import numpy as np
 
 from helpers import (load_env, oracle_game, do_nothing, set_line_switch, set_substation_switches,
@@ -233,28 +235,39 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
     rng = np.random.default_rng(seed)
     eng.reset()
     orc.reset()
-    stats = dict(done=0, illegal=0, split_buses=0)
+    stats = dict(done=0, illegal=0, split_buses=0, dropped=0)
+    # Environments in which a bus voltage has collapsed to ~0 (a zero-injection busbar left dangling by a random split:
+    # Newton converges super-linearly to the spurious V = 0 root) are dropped from the comparison from then on: whether
+    # |V| ends at exactly 0 or at 1e-39 is rounding luck, and the ampere flow of its lines is then NaN or finite --
+    # which flips overflow cuts.  numpy/SuperLU in the reference is exposed to the same luck; it is not a parity matter.
+    tracked = np.ones(batch, dtype=bool)
     for t in range(steps):
         acts = random_actions(case, rng, batch)
         ve, vo = eng.is_action_valid(acts), orc.is_action_valid(acts)
-        assert np.array_equal(ve, vo), 'is_action_valid differs at step %d' % t
+        assert np.array_equal(ve[tracked], vo[tracked]), 'is_action_valid differs at step %d' % t
         eng.step(acts, auto_reset=True)
         orc.step(acts, auto_reset=True)
+        bt_e, bt = eng.read('BUS_TYPE'), orc.read('BUS_TYPE')
+        min_vm = np.zeros(batch)
+        assert orc._lib._lib.orc_debug_min_vm(orc._h, min_vm.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        tracked &= ~(min_vm < 1e-6)     # smallest |V| of an active bus over this step's successful solves (oracle side)
+        k = tracked
         for f in ('DONE', 'FLAG', 'ILLEGAL', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES',
                   'LINES_EX_NODES', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN', 'SOFT_COUNT', 'CHRONIC_ROW',
                   'CHRONIC_SLOT', 'N_LOADS_CUT', 'N_PRODS_CUT', 'CASCADE_DEPTH', 'N_SOLVES'):
-            a, b = eng.read(f), orc.read(f)
+            a, b = eng.read(f)[k], orc.read(f)[k]
             assert np.array_equal(a, b), '%s differs at step %d (envs %s)' % (
-                f, t, np.where((a != b).reshape(batch, -1).any(axis=1))[0][:8])
+                f, t, np.where(k)[0][np.where((a != b).reshape(int(k.sum()), -1).any(axis=1))[0][:8]])
         assert int((eng.read('FLAG') == 4).sum()) == 0, 'engine capacity error'
-        bt = orc.read('BUS_TYPE')
-        live = bt != 4
-        assert np.array_equal(eng.read('BUS_TYPE') != 4, live)
+        live = (bt != 4) & k[:, None]
+        assert np.array_equal((bt_e != 4) & k[:, None], live)
         np.testing.assert_allclose(eng.read('VM')[live], orc.read('VM')[live], rtol=0, atol=1e-8)
         np.testing.assert_allclose(np.deg2rad(eng.read('VA')[live]), np.deg2rad(orc.read('VA')[live]), rtol=0, atol=1e-8)
-        np.testing.assert_allclose(eng.read('AMPS'), orc.read('AMPS'), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(eng.read('QG'), orc.read('QG'), rtol=0, atol=1e-5)
-        stats['done'] += int(orc.read('DONE').sum())
-        stats['illegal'] += int((orc.read('ILLEGAL') != 0).sum())
+        np.testing.assert_allclose(eng.read('AMPS')[k], orc.read('AMPS')[k], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(eng.read('QG')[k], orc.read('QG')[k], rtol=0, atol=1e-5)
+        stats['done'] += int(orc.read('DONE')[k].sum())
+        stats['illegal'] += int((orc.read('ILLEGAL')[k] != 0).sum())
         stats['split_buses'] = max(stats['split_buses'], int((bt[:, case.nS:] != 4).sum(axis=1).max()))
+    stats['dropped'] = int((~tracked).sum())
+    assert stats['dropped'] <= max(2, batch // 10), 'too many environments dropped as degenerate: %d' % stats['dropped']
     return stats

@@ -13,8 +13,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 NAMES = ['A-C types/compaction', 'adjacency', 'symbolic', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
-         'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)', 'LU: bounds+prefetch', 'LU: phase0',
-         'LU: phase1', 'LU: phase2']
+         'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)']
 
 
 def main():
@@ -37,6 +36,7 @@ def main():
     eng.step(act, auto_reset=True)
     zero = np.zeros((B, 16), dtype=np.int64)
     eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
+    eng.kernel_time(reset=True)
     s0, i0 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
     for _ in range(steps):
         eng.step(act, auto_reset=True)
@@ -48,8 +48,15 @@ def main():
     nsolve, nit = float(s1 - s0), float(i1 - i0)
     print('B=%d steps=%d solves=%d iterations=%d' % (B, steps, nsolve, nit))
     for k, name in enumerate(NAMES):
-        per = tot[k] / (nit if k in (4, 5, 6, 11, 12, 13, 14) else nsolve)
-        print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, 'iteration' if k in (4, 5, 6, 11, 12, 13, 14) else 'solve'))
+        per = tot[k] / (nit if k in (4, 5, 6) else nsolve)
+        print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, 'iteration' if k in (4, 5, 6) else 'solve'))
+    # whole kernel body per environment: shader cycles (clock64) and 100 MHz wall ticks (wall_clock64)
+    kt = eng.kernel_time()
+    body_c, body_w = tot[14], tot[15] * 1e-8
+    print('step kernel body: %.0f cyc and %.1f us per env-step -> shader clock %.0f MHz under load'
+          % (body_c / (B * steps), body_w / (B * steps) * 1e6, body_c / body_w * 1e-6))
+    print('step kernel: %.3f ms per launch (HIP events, %d launches); mean resident environments = sum of body wall times / '
+          'kernel time = %.0f (of %d slots = 256 CUs x 4)' % (kt[0] / kt[1], kt[1], body_w * 1e3 / kt[0], 1024))
 
 
 if __name__ == '__main__':
