@@ -107,6 +107,8 @@ struct DevCase {
   const int *lvl_start;  // [nlev+1] start of each level inside lvl_row
   int nlev;
   int MCAP, TCAP;        // schedule capacities: pivot-neighbour pairs, update triples
+  // per-environment schedule cache (global memory): byte offsets of its tables inside one environment's blob
+  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_le4, co_ly4, co_ymeta, co_lvl, cache_stride;
   const int *sub_le_ptr; // [nS+1]  CSR of line ends per substation
   const int *sub_le;     //         (line << 1) | end   (end 0 = origin, 1 = extremity)
   const int *elem_sub;   // [ntopo] substation of each element of [prods | loads | lines_or | lines_ex]
@@ -136,6 +138,7 @@ struct DevState {
   // per-environment solve workspace (L2-resident, streamed sequentially by the numeric phases)
   u64 *ws_tri, *ws_pair;           // [TCAP], [MCAP] update triples / (pivot, neighbour) pairs with entry indices
   unsigned *ws_piv;                // [NB] pivots (diagonal entry | k << 16)
+  u8 *ws_cache;                    // [cache_stride] schedule cache: header, node-assignment signature, index tables
 };
 
 // LDS carve-up (pointers into the workgroup's dynamic shared memory).  The arrays of the "setup" group are only
@@ -146,8 +149,7 @@ struct Smem {
   double *lu;
   double *vm, *va, *vc, *ivm, *psp, *qsp, *mr, *mi, *rhs;   // vc: V = vc[2i] + j vc[2i+1]; ivm: 1 / |V_i|
   u16 *int2row, *lvlp, *lvlm, *lvlt, *ediag;
-  u8 *row2int, *nv, *st, *on, *en, *pn, *ln, *lf, *lt;
-  u16 *le4;      // entry indices of the 4 blocks of every line: lives in the unused tail of lu (scalar solvers only)
+  u8 *row2int, *r2s, *nv, *st, *on, *en, *pn, *ln, *lf, *lt;   // r2s: bus row -> schedule index (superset), row2int: live buses only
   // setup group (aliases lu)
   u64 *adj0, *adjF;
   double *yre, *yim, *gvg, *amps;
@@ -178,19 +180,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) 
   PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
   PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
   PPN_TAKE(over, u8, nl)
-  // le4 must survive into the scalar solvers (DC / fast-decoupled), whose matrices use at most 2*ECAP doubles; it is
-  // written while building the schedule, when gvg (phase C) and the decoded action are dead: it overlays them
-  {
-    const size_t scalar_lu = 2 * (size_t)d.ECAP * 8;
-    if (o < scalar_lu) o = (scalar_lu + 15) & ~(size_t)15;
-  }
-  S.le4 = (u16*)(base + o);
-  {
-    const size_t o0 = o;
-    PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
-    const size_t need = ((nl * 4 * 2) + 15) & ~(size_t)15;
-    if (o - o0 < need) o = o0 + need;
-  }
+  PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
   const size_t setup_bytes = o;
   const size_t lu_bytes = (size_t)d.LUCAP * 8;
   S.lu = (double*)base;
@@ -202,7 +192,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) 
   PPN_TAKE(int2row, u16, NB * 2)
   PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
   PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(ediag, u16, NB * 2)
-  PPN_TAKE(row2int, u8, nrows) PPN_TAKE(nv, u8, NB)
+  PPN_TAKE(row2int, u8, nrows) PPN_TAKE(r2s, u8, nrows) PPN_TAKE(nv, u8, NB)
   PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
   PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl)
 #undef PPN_TAKE

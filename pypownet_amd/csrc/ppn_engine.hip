@@ -310,7 +310,8 @@ static int alloc_state(ppn_engine* e, DevState* s) {
   s->prof = dalloc<long long>(e, B * 16);
   s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
   s->ws_piv = dalloc<unsigned>(e, B * d.NB);
-  return s->ws_piv ? 0 : -1;
+  s->ws_cache = dalloc<u8>(e, B * (size_t)d.cache_stride);   // zero-filled: header.valid == 0
+  return (s->ws_piv && s->ws_cache) ? 0 : -1;
 }
 
 struct FieldInfo { size_t elem; int n; size_t off; };   // off: byte offset of the pointer inside DevState
@@ -494,6 +495,16 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     }
     int maxl = 0;
     for (int k = 0; k < nS; ++k) maxl = std::max(maxl, level[k]);
+    if (getenv("PPN_VERBOSE")) {   // schedule shape of the base topology: pivots / pairs / triples per level
+      std::vector<int> np_(maxl + 1, 0), nm_(maxl + 1, 0), nt_(maxl + 1, 0);
+      for (int k = 0; k < nS; ++k) {
+        int c = 0;
+        for (int j = k + 1; j < nS; ++j) if (filled[k][j]) ++c;
+        np_[level[k]]++; nm_[level[k]] += c; nt_[level[k]] += c * c;
+      }
+      for (int lv = 0; lv <= maxl; ++lv) fprintf(stderr, "[ppn] level %2d: %3d pivots %4d pairs %5d triples\n", lv, np_[lv], nm_[lv], nt_[lv]);
+      fprintf(stderr, "[ppn] filled block entries %d, pairs %d, triples %d\n", pairs, base_pairs, base_tri);
+    }
     nlev = 2 * (maxl + 1);                   // busbar (s, node) sits in level 2*level(s) + node
     lvl_start.assign(nlev + 1, 0);
     int w = 0;
@@ -552,6 +563,15 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.ECAP = (ecap + 7) & ~7;
   d.LUCAP = 4 * d.ECAP;
   if (d.ECAP > 16000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds 16-bit entry indices"); }
+  {   // schedule cache blob of one environment
+    size_t o = 64;                      // header: 16 ints
+    auto take = [&](int* off, size_t bytes) { *off = (int)o; o += (bytes + 15) & ~(size_t)15; };
+    take(&d.co_sig, (size_t)d.ntopo); take(&d.co_r2s, (size_t)nrows); take(&d.co_i2r, (size_t)NB * 2);
+    take(&d.co_ediag, (size_t)NB * 2); take(&d.co_ydiag, (size_t)NB * 2);
+    take(&d.co_le4, (size_t)nl * 8); take(&d.co_ly4, (size_t)nl * 8);
+    take(&d.co_ymeta, (size_t)d.YCAP * 4); take(&d.co_lvl, (size_t)(nlev + 1) * 8);
+    d.cache_stride = (int)o;
+  }
   { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); }
   if (e->lds_bytes > 160 * 1024) {
     free_all(e); delete e;

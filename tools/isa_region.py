@@ -30,7 +30,7 @@ def main():
     for l in text:
         if re.match(r'^_Z10ppn_kernel' + kern + r'.*:', l):
             inside = True
-        if inside and 's_endpgm' in l:
+        if inside and l.startswith('.Lfunc_end'):
             inside = False
         if not inside:
             continue
