@@ -75,6 +75,8 @@ struct ppn_engine {
   u8* d_actions = nullptr;
   double* d_obs = nullptr;
   u8* d_valid = nullptr;
+  int* d_perm = nullptr;            // launch order of the step kernel
+  bool order_launches = true;       // PPN_LAUNCH_ORDER=0 disables the loading-ordered launch (A/B measurements)
   int* d_ids = nullptr;     // scratch for ppn_reset: env ids, slots, t0 (3 * batch)
   ppn_rules rules;
   // kernel timing
@@ -128,6 +130,7 @@ struct KArgs {
   const int *ids, *slots, *t0;
   double* obs;
   int sim, auto_reset;
+  const int* perm;      // launch order of the step kernel: workgroup b runs environment perm[b] (null: b)
 };
 
 #ifndef PPN_EMU
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPN_WAV
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Smem S;
   ppn_carve(a.d, W, smem, &S);
-  const int env = blockIdx.x;
+  const int env = (KIND == K_STEP && a.perm) ? a.perm[blockIdx.x] : (int)blockIdx.x;
   const int lane0 = threadIdx.x;
   if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, lane0);
   else if (KIND == K_GAMEOVER) body_game_over<W>(a.d, a.st, S, a.valid, env, lane0);
@@ -147,6 +150,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPN_WAV
   else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, lane0);
   else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, lane0);
   else if (KIND == K_OBS) body_obs(a.d, a.st, S, a.obs, env, lane0);
+}
+#endif
+
+#ifndef PPN_EMU
+// Launch order of the step kernel.  Environment steps differ in length by an order of magnitude (one 3-iteration solve
+// ... a six-solve cascade ending in a diverging 10-iteration solve and a restart), and a launch of `batch` workgroups
+// over 1024 resident slots ends with its longest chains: started in index order the machine idles ~40 % of the launch.
+// The largest loading (ampere flow / thermal limit) left by the previous step predicts the long ones well enough
+// (overflowed lines -> cuts, re-solves, divergence), so the workgroups are handed out by decreasing loading: a counting
+// sort over 256 loading classes, one workgroup.
+#define PPN_ORDER_BINS 256
+__global__ void __launch_bounds__(1024) ppn_order_kernel(const float* prio, int* perm, int n) {
+  __shared__ int hist[PPN_ORDER_BINS];
+  __shared__ int offs[PPN_ORDER_BINS];
+  const int t = threadIdx.x;
+  if (t < PPN_ORDER_BINS) hist[t] = 0;
+  __syncthreads();
+  auto bin_of = [](float p) {
+    if (!(p == p)) p = 2.5f;                       // NaN loading (a collapsed voltage): treat as heavy
+    int b = (int)((2.5f - p) * (PPN_ORDER_BINS / 2.0f));   // 2.5 -> class 0 (first), 0.5 -> last
+    return b < 0 ? 0 : (b >= PPN_ORDER_BINS ? PPN_ORDER_BINS - 1 : b);
+  };
+  for (int i = t; i < n; i += 1024) atomicAdd(&hist[bin_of(prio[i])], 1);
+  __syncthreads();
+  if (t == 0) { int run = 0; for (int b = 0; b < PPN_ORDER_BINS; ++b) { offs[b] = run; run += hist[b]; } }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) perm[atomicAdd(&offs[bin_of(prio[i])], 1)] = i;
 }
 #endif
 
@@ -308,6 +338,7 @@ static int alloc_state(ppn_engine* e, DevState* s) {
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
   s->prof = dalloc<long long>(e, B * 16);
+  s->prio = dalloc<float>(e, B);
   s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
   s->ws_piv = dalloc<unsigned>(e, B * d.NB);
   s->ws_cache = dalloc<u8>(e, B * (size_t)d.cache_stride);   // zero-filled: header.valid == 0
@@ -610,6 +641,8 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (alloc_state(e, &e->st) || alloc_state(e, &e->sim)) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
   e->d_actions = dalloc<u8>(e, (size_t)batch * d.alen);
   e->d_valid = dalloc<u8>(e, batch);
+  e->d_perm = dalloc<int>(e, batch);
+  { const char* v = getenv("PPN_LAUNCH_ORDER"); if (v && v[0] == '0') e->order_launches = false; }
   e->d_ids = dalloc<int>(e, (size_t)3 * batch);
   e->d_obs = dalloc<double>(e, (size_t)batch * d.obslen);
   if (!e->d_obs) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
@@ -760,6 +793,12 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
   if (simulate) { if (copy_state(e, &e->sim, &e->st)) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err()); }
   KArgs a = make_args(e, simulate != 0);
   a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = (auto_reset && !simulate) ? 1 : 0;
+#ifndef PPN_EMU
+  if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first
+    hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch);
+    a.perm = e->d_perm;
+  }
+#endif
   if (launch<K_STEP>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   if (a.auto_reset && e->maybe_dead) {
     // environments that were already over when the step began (after ppn_reset or after steps without auto_reset) did
