@@ -98,7 +98,7 @@ struct DevCase {
   const int *gen_sub, *load_sub, *or_sub, *ex_sub;       // substation index of each element
   const int *sub_load;                                   // [nS] load index at substation or -1
   const double *gen_qmax, *gen_qmin, *gen_qg0;           // [nP]  (qg0: case value of gen[:,QG])
-  const double *ly;      // [nl*8]  yff.re, yff.im, yft.re, yft.im, ytf.re, ytf.im, ytt.re, ytt.im  (status on)
+  const double *ly;      // [8][nl] component-major: yff.re, yff.im, yft.re, yft.im, ytf.re, ytf.im, ytt.re, ytt.im  (status on)
   const double *lb;      // [nl*10] B' (ff,ft,tf,tt), B'' (ff,ft,tf,tt), bdc, pfinj
   const int *pos_row;    // [nrows] bus row at elimination position p (static min-degree order, twins adjacent)
   // static level schedule of the elimination forest of the base graph (valid for every topology obtained by line

@@ -569,6 +569,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   int NB = r->max_active_buses > 0 ? std::min(r->max_active_buses, nrows) : nrows;
   if (NB < 2) NB = 2;
   if (NB > 254) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "more than 254 active busbars are not supported"); }
+  if (NB < nS) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "max_active_buses (%d) is below the number of substations (%d)", NB, nS); }
   d.NB = NB;
   e->W = (NB + 63) / 64;
   d.YCAP = NB + 2 * nl;
@@ -614,7 +615,12 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.or_sub = upload(e, or_sub, e->allocs); d.ex_sub = upload(e, ex_sub, e->allocs);
   d.sub_load = upload(e, sub_load, e->allocs);
   d.gen_qmax = upload(e, qmax, e->allocs); d.gen_qmin = upload(e, qmin, e->allocs); d.gen_qg0 = upload(e, qg0, e->allocs);
-  d.ly = upload(e, ly, e->allocs); d.lb = upload(e, lb, e->allocs);
+  {   // component-major copy of the line admittances: lanes of a wave read consecutive lines -> coalesced
+    std::vector<double> lyt((size_t)nl * 8);
+    for (int l = 0; l < nl; ++l) for (int c = 0; c < 8; ++c) lyt[(size_t)c * nl + l] = ly[(size_t)l * 8 + c];
+    d.ly = upload(e, lyt, e->allocs);
+  }
+  d.lb = upload(e, lb, e->allocs);
   d.pos_row = upload(e, pos_row, e->allocs);
   d.lvl_row = upload(e, lvl_row, e->allocs); d.lvl_start = upload(e, lvl_start, e->allocs);
   d.sub_le_ptr = upload(e, le_ptr, e->allocs); d.sub_le = upload(e, le, e->allocs);
