@@ -29,21 +29,35 @@ struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LD
 #define LANE_ARR(type, name, n) type name[64][n]
 #define LV(name) name[lane]
 #define LANE_READ(v, l) ((v)[(l)])          // value held by lane l (l wave-uniform)
+#define LANE_READ_D(arr, j, l) ((arr)[(l)][(j)])   // element j of a per-lane double array, as held by lane l
+#define LANE_READ_DV(v, l) ((v)[(l)])
 #define PPN_UNI(x) (x)
 static inline int ppn_popc(u64 x) { return __builtin_popcountll(x); }
 static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #else
 #define PPN_DEV __device__ __forceinline__
 #define LANE_LOOP for (int lane = lane0, once_ = 1; once_; once_ = 0)
-// One wavefront per workgroup: LDS operations of a wave execute in order, so ordering LDS phases only needs the
-// compiler not to move memory accesses across the point (and pending LDS results to have landed).  Global loads
-// may stay in flight across WSYNC (prefetched schedule records); WSYNC_G also orders global memory.
+// One wavefront per workgroup: the LDS unit executes the DS instructions of a wave in issue order (a ds_read issued
+// after a ds_write / ds_add of any lane of the same wave observes it), so ordering LDS phases only needs the COMPILER
+// not to move memory accesses across the point; the waits for loaded registers are the compiler's own.  Nothing is
+// drained: stores and atomics of a phase complete underneath the loads of the next one.  (-DPPN_WSYNC_WAIT restores
+// an s_waitcnt lgkmcnt(0) at every phase boundary.)  Global loads stay in flight across WSYNC (prefetched schedule
+// records); WSYNC_G also orders global memory.
+#ifdef PPN_WSYNC_WAIT
 #define WSYNC() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define WSYNC() __asm__ volatile("" ::: "memory")
+#endif
 #define WSYNC_G() __syncthreads()
 #define LANE_VAR(type, name) type name
 #define LANE_ARR(type, name, n) type name[n]
 #define LV(name) name
 #define LANE_READ(v, l) ((unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
+#define LANE_READ_D(arr, j, l) ppn_readlane_d((arr)[(j)], (l))
+#define LANE_READ_DV(v, l) ppn_readlane_d((v), (l))
+__device__ __forceinline__ double ppn_readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 #define PPN_UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ int ppn_popc(u64 x) { return __popcll(x); }
 __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
@@ -108,7 +122,7 @@ struct DevCase {
   int nlev;
   int MCAP, TCAP;        // schedule capacities: pivot-neighbour pairs, update triples
   // per-environment schedule cache (global memory): byte offsets of its tables inside one environment's blob
-  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_le4, co_ly4, co_ymeta, co_lvl, cache_stride;
+  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, cache_stride;
   const int *sub_le_ptr; // [nS+1]  CSR of line ends per substation
   const int *sub_le;     //         (line << 1) | end   (end 0 = origin, 1 = extremity)
   const int *elem_sub;   // [ntopo] substation of each element of [prods | loads | lines_or | lines_ex]
