@@ -602,7 +602,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     take(&d.co_ediag, (size_t)NB * 2); take(&d.co_ydiag, (size_t)NB * 2);
     take(&d.co_le4, (size_t)nl * 8); take(&d.co_ly4, (size_t)nl * 8);
     take(&d.co_ymeta, (size_t)d.YCAP * 4); take(&d.co_lvl, (size_t)(nlev + 1) * 8);
-    take(&d.co_tail, 16 + 128);         // dense tail: 8 bus indices (+pad), 8 x 8 entry map (u16)
+    take(&d.co_tail, 32 + 512);         // dense tail: up to 16 bus indices (+pad), up to 16 x 16 entry map (u16)
     d.cache_stride = (int)o;
   }
   { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); }

@@ -13,7 +13,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 NAMES = ['live buses/types/connectivity', 'schedule check (+rebuild)', '(unused)', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
-         'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)']
+         'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)', 'restart of ended episodes (incl its solves)',
+         'cut flags + topology write-back']
 
 
 def main():
@@ -48,8 +49,9 @@ def main():
     nsolve, nit = float(s1 - s0), float(i1 - i0)
     print('B=%d steps=%d solves=%d iterations=%d' % (B, steps, nsolve, nit))
     for k, name in enumerate(NAMES):
-        per = tot[k] / (nit if k in (4, 5, 6) else nsolve)
-        print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, 'iteration' if k in (4, 5, 6) else 'solve'))
+        unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
+        per = tot[k] / {'iteration': nit, 'env-step': float(B * steps), 'solve': nsolve}[unit]
+        print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
     # whole kernel body per environment: shader cycles (clock64) and 100 MHz wall ticks (wall_clock64)
     kt = eng.kernel_time()
     body_c, body_w = tot[14], tot[15] * 1e-8
