@@ -56,6 +56,18 @@ def bench_limits(case):
     return lim
 
 
+def measured_traffic(batch):
+    """HBM bytes per step-kernel launch from the rocprofv3 PMC passes of this build (FETCH_SIZE x 2 + WRITE_SIZE, collected
+    by tools/collect_profiles.sh, summary committed under profiles/); None when no summary matches this batch size --
+    counters cannot be collected from inside the timed run."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
+            p = json.load(f)
+        return float(p['hbm_bytes_per_launch']) if int(p['batch']) == int(batch) else None
+    except Exception:
+        return None
+
+
 def env_assignment(first, count, chronics):
     ids = np.arange(first, first + count)
     slots = (ids % len(chronics)).astype(np.int32)
@@ -189,7 +201,7 @@ def main():
                        'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
                        'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
                          'kernel': 'ppn_kernel<W=2,K_STEP>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
                          'algorithmic_bytes_per_env_step': b_step},
             'cpu_baseline': None,
