@@ -102,8 +102,25 @@ def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
         el = time.perf_counter() - t
         if el > budget_s or steps >= 4000:
             break
-    return {'value': nb * steps / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle with OpenMP over envs' % (nb, steps, el)}
+    out = {'value': nb * steps / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+           'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle with OpenMP over envs' % (nb, steps, el)}
+    # the "reference-equivalent Python backend" -- the numpy/scipy restatement of the PYPOWER path
+    # (scipy.sparse + SuperLU, the library class the reference uses), one environment on one host core, same workload
+    try:
+        from oracle.game_np import OracleGame
+        g = OracleGame(case, conf, chronics, thermal_limits=limits)
+        a1 = np.zeros(case.action_length, dtype=np.int64)
+        t = time.perf_counter()
+        n1 = 0
+        while time.perf_counter() - t < 4.0:
+            if g.step(a1)[3]:
+                g.process_game_over()
+            n1 += 1
+        out['python_restatement'] = {'value': n1 / (time.perf_counter() - t), 'unit': 'env-steps/s', 'cores': 1,
+                                     'sample': '1 env x %d steps, oracle/game_np.py (numpy + scipy SuperLU)' % n1}
+    except Exception as ex:
+        out['python_restatement'] = {'value': None, 'sample': 'failed: %s' % ex}
+    return out
 
 
 def main():
