@@ -148,7 +148,7 @@ struct DevState {
   int *rec, *lcd, *ncd, *soft;     // counters
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
-  long long* prof;                 // [16] cycle counters per phase (only written by -DPPN_PROF builds)
+  long long* prof;                 // [32] cycle counters per phase (only written by -DPPN_PROF builds)
   float* prio;                     // expected cost of the NEXT step (largest ampere flow / limit after this one): launch order
   // per-environment solve workspace (L2-resident, streamed sequentially by the numeric phases)
   u64 *ws_tri, *ws_pair;           // [TCAP], [MCAP] update triples / (pivot, neighbour) pairs with entry indices

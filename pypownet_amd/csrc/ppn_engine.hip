@@ -337,7 +337,7 @@ static int alloc_state(ppn_engine* e, DevState* s) {
   s->flag = dalloc<int>(e, B); s->ill = dalloc<int>(e, B); s->depth = dalloc<int>(e, B);
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
-  s->prof = dalloc<long long>(e, B * 16);
+  s->prof = dalloc<long long>(e, B * 32);
   s->prio = dalloc<float>(e, B);
   s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
   s->ws_piv = dalloc<unsigned>(e, B * d.NB);
@@ -350,7 +350,7 @@ struct FieldInfo { size_t elem; int n; size_t off; };   // off: byte offset of t
 static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* writable) {
   const DevCase& d = e->dc;
   if ((int)f == 100) {   /* phase cycle counters of -DPPN_PROF builds (tools/profile_phases.py) */
-    fi->elem = sizeof(long long); fi->n = 16; fi->off = offsetof(DevState, prof); *writable = true; return true;
+    fi->elem = sizeof(long long); fi->n = 32; fi->off = offsetof(DevState, prof); *writable = true; return true;
   }
 #define FI(member, type, count, w) { fi->elem = sizeof(type); fi->n = (count); fi->off = offsetof(DevState, member); *writable = (w); return true; }
   switch (f) {
@@ -578,7 +578,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     if (d.YCAP > 64 * ypl) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "Ybus of this case (%d entries) exceeds the register budget of the W=%d kernel", d.YCAP, e->W); }
   }
   d.nlev = nlev;
-  if (nlev + 1 > 128) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "elimination forest deeper than 63 substation levels"); }
+  if (nlev + 1 > 64) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "elimination forest deeper than 31 substation levels"); }
   {
     const double grow = 1.3 + 1.7 * ((NB > nS) ? (double)(NB - nS) / nS : 0.0);   // node splitting adds busbars and fill
     d.MCAP = ((int)(base_pairs * grow) + 64 + 15) & ~15;

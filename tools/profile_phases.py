@@ -35,7 +35,7 @@ def main():
     eng.reset(chronic_slot=slots, t0=t0)
     act = np.zeros((B, case.action_length), dtype=np.uint8)
     eng.step(act, auto_reset=True)
-    zero = np.zeros((B, 16), dtype=np.int64)
+    zero = np.zeros((B, 32), dtype=np.int64)
     eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
     eng.kernel_time(reset=True)
     s0, i0 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
@@ -43,7 +43,7 @@ def main():
         eng.step(act, auto_reset=True)
     eng.sync()
     s1, i1 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
-    out = np.zeros((B, 16), dtype=np.int64)
+    out = np.zeros((B, 32), dtype=np.int64)
     eng._check(eng._lib.ppn_read(eng._h, 100, out.ctypes.data, out.nbytes, 1, 0), 'read prof')
     tot = out.sum(axis=0).astype(np.float64)
     nsolve, nit = float(s1 - s0), float(i1 - i0)
@@ -52,6 +52,8 @@ def main():
         unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
         per = tot[k] / {'iteration': nit, 'env-step': float(B * steps), 'solve': nsolve}[unit]
         print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
+    for k, name in ((16, 'LU level bounds + record prefetch'), (17, 'LU phase 0 (invert, y\')'), (18, 'LU phase 1 (U\', forward)'), (19, 'LU phase 2 (Schur)')):
+        print('%-28s total %.3e cyc  %8.0f cyc per iteration' % (name, tot[k], tot[k] / nit))
     # whole kernel body per environment: shader cycles (clock64) and 100 MHz wall ticks (wall_clock64)
     kt = eng.kernel_time()
     body_c, body_w = tot[14], tot[15] * 1e-8
