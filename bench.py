@@ -141,9 +141,14 @@ def main():
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
+    # PPN_BENCH_BACKEND=gloo: smoke test of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices;
+    # the numbers mean nothing then).  The driver's runs use the default: one GPU per rank, RCCL.
+    backend = os.environ.get('PPN_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL over xGMI
+        dist.init_process_group(backend, rank=rank, world_size=world)   # nccl = RCCL over xGMI
 
     from pypownet_amd.engine import Engine
     case, conf, chronics = load_workload()
@@ -180,7 +185,7 @@ def main():
     ns1, ni1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
     done_now = int(eng.read('DONE').sum())
     stats = torch.tensor([elapsed, float(ns1 - ns0), float(ni1 - ni0), kms, float(klaunch)], dtype=torch.float64,
-                         device='cuda:%d' % local_rank)
+                         device=('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu')
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
