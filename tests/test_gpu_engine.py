@@ -64,3 +64,30 @@ def test_gpu_random_actions_vs_c_oracle(env, solver, steps, batch):
     full-capacity (every busbar may be active) W=4 kernels are the ones exercised on default118."""
     st = ec.check_random_actions_vs_c_oracle(HIP, env, steps, batch, solver)
     assert st['split_buses'] > 0 and st['illegal'] > 0
+
+
+def test_gpu_launch_order_does_not_change_results(monkeypatch):
+    """The loading-ordered launch (ppn_order_kernel, batches above the 1024 resident slots) only changes WHEN an
+    environment runs: every field must be bit-identical with the ordering switched off (PPN_LAUNCH_ORDER=0)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    import bench
+    from pypownet_amd.engine import Engine
+    case, conf, chronics = bench.load_workload()
+    B = 2048
+    slots, t0 = bench.env_assignment(0, B, chronics)
+    act = np.zeros((B, case.action_length), dtype=np.uint8)
+    states = []
+    for order in ('1', '0'):
+        monkeypatch.setenv('PPN_LAUNCH_ORDER', order)
+        eng = Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
+        eng.reset(chronic_slot=slots, t0=t0)
+        for _ in range(8):
+            eng.step(act, auto_reset=True)
+        states.append({f: eng.read(f).copy() for f in ('VM', 'VA', 'AMPS', 'PG', 'QG', 'LINES_STATUS', 'DONE', 'FLAG',
+                                                       'SOFT_COUNT', 'RECONNECTABLE', 'CHRONIC_ROW', 'N_SOLVES', 'N_ITERS')})
+        del eng
+    for f in states[0]:
+        assert np.array_equal(states[0][f], states[1][f], equal_nan=True), f
+    assert int(states[0]['N_SOLVES'].sum()) > 8 * B      # cascades did happen
