@@ -72,6 +72,7 @@ def run(name, envname, solver, batch, steps, limits=None, split=False, max_activ
                       'batch': batch, 'steps': steps, 'solver': solver, 'step_kernel_ms': kms / max(kn, 1),
                       'solves_per_step': float(s1 - s0) / (batch * steps), 'iters_per_solve': float(i1 - i0) / max(float(s1 - s0), 1.0),
                       'lds_bytes_per_env': eng.lds_bytes, 'illegal_fraction': float((eng.read('ILLEGAL') != 0).mean()),
+                      'engine_capacity_flags_last_step': int((eng.read('FLAG') == 4).sum()),
                       'done_fraction_last_step': float(eng.read('DONE').mean())}), flush=True)
 
 
@@ -86,6 +87,8 @@ def main():
         4096, steps, limits=lim118, max_active=case118.nS)
     run('configs[4] share of one GPU: default118 AC Newton-Raphson, random node splitting every step, batch 1024, all 236 '
         'busbars may be active', 'default118', 'newton', 1024, steps, limits=lim118, split=True)
+    run('the same with max_active_buses = 128 (W = 2 kernels; a topology with more live busbars would report flag 4)',
+        'default118', 'newton', 1024, steps, limits=lim118, split=True, max_active=128)
 
 
 if __name__ == '__main__':
