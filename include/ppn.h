@@ -90,7 +90,9 @@ typedef struct ppn_rules {
   int32_t max_number_actionned_total;
   int32_t game_over_mode_hard;        /* RunEnv(game_over_mode='hard'): next chronic after a game over */
   int32_t chronic_looping;            /* PPN_LOOP_* */
-  /* engine capacities (0 = safe default: every busbar may be active) */
+  /* engine capacities (0 = safe default: every busbar may be active).  max_active_buses bounds the busbars with a line
+   * attached in any one topology (at least the number of substations; at most 254) and sizes the LDS working set; a
+   * topology that exceeds a capacity reports PPN_FLAG_ENGINE_CAPACITY for that environment. */
   int32_t max_active_buses;
   int32_t lu_capacity;                /* doubles of LU storage per environment, 0 = auto */
 } ppn_rules;

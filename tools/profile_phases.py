@@ -52,8 +52,7 @@ def main():
         unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
         per = tot[k] / {'iteration': nit, 'env-step': float(B * steps), 'solve': nsolve}[unit]
         print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
-    for k, name in ((16, 'LU level bounds + record prefetch'), (17, 'LU phase 0 (invert, y\')'), (18, 'LU phase 1 (U\', forward)'), (19, 'LU phase 2 (Schur)'),
-                    (20, 'eval pass 0 (sincos, zero)'), (21, 'eval pass 1 (Ybus entries)'), (22, 'eval pass 2 (buses, norm)')):
+    for k, name in ((16, 'LU level bounds + record prefetch'), (17, 'LU phase 0 (invert, y\')'), (18, 'LU phase 1 (U\', forward)'), (19, 'LU phase 2 (Schur)')):
         print('%-28s total %.3e cyc  %8.0f cyc per iteration' % (name, tot[k], tot[k] / nit))
     # whole kernel body per environment: shader cycles (clock64) and 100 MHz wall ticks (wall_clock64)
     kt = eng.kernel_time()
