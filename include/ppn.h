@@ -149,6 +149,12 @@ typedef enum ppn_field {
   PPN_F_SUCCESS,           /* u8 [1]    success flag of the last solve                         */
   PPN_F_OBSERVATION,       /* f64 [obs_len] Observation.as_array() (environment.py:583-595)    */
   PPN_F_BUS_TYPE,          /* u8 [2nS]  bus type of the last solve: 1 PQ, 2 PV, 3 REF, 4 isolated */
+  PPN_F_REWARD,            /* f64 [5]   reward of the last step: [loads cut, productions cut, action cost (+ illegal-action
+                                        penalties), distance to the initial topology, line usage] (ppn_set_reward)      */
+  PPN_F_ILLEGAL_COUNTS,    /* i32 [3]   IllegalActionException contents as counts: broken-line reconnections, on-cooldown
+                                        line switches, on-cooldown substations (game.py:650-753)                         */
+  PPN_F_ACTION_SWITCHES,   /* i32 [2]   node switches, line-status switches of the action as the caller sees it after the
+                                        step: repaired in place, zeroed when the whole action was rejected (game.py:813)  */
   PPN_F_COUNT
 } ppn_field;
 
@@ -157,6 +163,28 @@ typedef enum ppn_field {
 int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, int32_t device, ppn_engine** out);
 int ppn_destroy(ppn_engine* e);
 const char* ppn_last_error(const ppn_engine* e);     /* e may be NULL: error of the last failed ppn_create */
+
+/* Coefficients of the five-component reward the reference's shipped environments use
+ * (CustomRewardSignal, parameters/default14/reward_signal.py:8-43; default118: the same with constant = 118).
+ * ppn_create installs the default14 values scaled by `constant = number of substations`; custom reward classes stay on
+ * the host (they see the Observation), this removes the per-step download of the observation for the shipped one. */
+typedef struct ppn_reward_params {
+  double line_usage;                   /* x sum((ampere / limit)^2)                      reward_signal.py:15, 110-111 */
+  double distance_initial_grid;        /* x number of elements not on their initial node reward_signal.py:17, 103-104 */
+  double number_loads_cut;             /* x isolated loads                               reward_signal.py:19, 95-96   */
+  double number_prods_cut;             /* x isolated productions                         reward_signal.py:20, 99-100  */
+  double loadflow_exception;           /* DivergingLoadflowException -> component 3      reward_signal.py:25, 50      */
+  double illegal_broken_line_switch;   /* per illegal reconnection of a broken line      reward_signal.py:29, 62-66   */
+  double illegal_oncooldown_line_switch;        /*                                       reward_signal.py:30, 68-73   */
+  double illegal_oncooldown_substation_switch;  /*                                       reward_signal.py:31, 75-81   */
+  double too_many_productions_cut;     /* TooManyProductionsCut -> component 1           reward_signal.py:34, 89      */
+  double too_many_consumptions_cut;    /* TooManyConsumptionsCut -> component 0          reward_signal.py:35, 91      */
+  double too_much_activated_elements;  /* action beyond the activation maxima            reward_signal.py:39, 58-59   */
+  double number_line_switches;         /* action cost per line-status switch             reward_signal.py:42, 137-138 */
+  double number_node_switches;         /* action cost per node switch                    reward_signal.py:43          */
+} ppn_reward_params;
+/* RewardSignal.compute_reward on the device (RunEnv.step computes it from the observation, environment.py:866-874). */
+int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p);
 
 /* ---- data ---------------------------------------------------------------------------------------- */
 /* Thermal limits in A (reference: Chronic.get_imaps() of the FIRST chronic, game.py:301-304). */

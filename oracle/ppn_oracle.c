@@ -70,6 +70,7 @@ typedef struct {
   uint8_t *pn, *ln, *on, *en, *st, *btype;
   int *rec, *lcd, *ncd, *soft;
   int done, dead, succ, flag, ill, depth, nsolve, niter, slot, row, nlc, npc, epoch;
+  int illn[3], actsw[2];   /* IllegalActionException contents as counts; node / line switches of the action after the step */
   double min_vm;    /* test diagnostic: smallest |V| of an active bus over the successful solves of the last step */
 } OEnv;
 
@@ -605,18 +606,25 @@ static int orc_apply_action(const OCase* c, OEnv* e, const uint8_t* action, int 
   int ns = 0, nln = 0, bits = 0;
   for (int s = 0; s < nS; ++s) ns += chg[s];
   for (int l = 0; l < nl; ++l) nln += a[ntopo + l];
+  int nb = 0, nc = 0, nn = 0, swn = 0, swl = nln;       /* counts behind the flag; switches of the action as seen after the step */
+  for (int k = 0; k < ntopo; ++k) swn += a[k];
   if (ns > c->R.max_number_actionned_substations || nln > c->R.max_number_actionned_lines || ns + nln > c->R.max_number_actionned_total) {
     bits = PPN_ILL_TOO_MANY;
     memset(a, 0, c->alen); memset(chg, 0, nS);
+    swn = 0; swl = 0;                 /* Action.set_as_do_nothing edits the caller's object in place (game.py:813) */
   } else {
-    for (int l = 0; l < nl; ++l) if (a[ntopo + l]) { if (e->rec[l] > 0) bits |= PPN_ILL_BROKEN_LINE; if (e->lcd[l] > 0) bits |= PPN_ILL_LINE_COOLDOWN; }
-    for (int s = 0; s < nS; ++s) if (chg[s] && e->ncd[s] > 0) bits |= PPN_ILL_NODE_COOLDOWN;
+    for (int l = 0; l < nl; ++l) if (a[ntopo + l]) { if (e->rec[l] > 0) { bits |= PPN_ILL_BROKEN_LINE; ++nb; } if (e->lcd[l] > 0) { bits |= PPN_ILL_LINE_COOLDOWN; ++nc; } }
+    for (int s = 0; s < nS; ++s) if (chg[s] && e->ncd[s] > 0) { bits |= PPN_ILL_NODE_COOLDOWN; ++nn; }
     if (bits && apply) {
       for (int l = 0; l < nl; ++l) if (e->rec[l] > 0 || e->lcd[l] > 0) a[ntopo + l] = 0;
       for (int k = 0; k < ntopo; ++k) { const int s = c->elem_sub[k]; if (chg[s] && e->ncd[s] > 0) a[k] = 0; }
       for (int s = 0; s < nS; ++s) if (e->ncd[s] > 0) chg[s] = 0;
+      swn = 0; swl = 0;
+      for (int k = 0; k < ntopo; ++k) swn += a[k];
+      for (int l = 0; l < nl; ++l) swl += a[ntopo + l];
     }
   }
+  if (apply) { e->illn[0] = nb; e->illn[1] = nc; e->illn[2] = nn; e->actsw[0] = swn; e->actsw[1] = swl; }
   if (apply) {
     for (int g = 0; g < nP; ++g) if (a[g]) e->pn[g] ^= 1;
     for (int q = 0; q < nL; ++q) if (a[nP + q]) e->ln[q] ^= 1;
@@ -850,6 +858,7 @@ static int field_ptr(const OCase* c, OEnv* e, ppn_field f, void** p, size_t* byt
     case PPN_F_RECONNECTABLE: A(e->rec, c->nl, int) case PPN_F_LINE_COOLDOWN: A(e->lcd, c->nl, int)
     case PPN_F_NODE_COOLDOWN: A(e->ncd, c->nS, int) case PPN_F_SOFT_COUNT: A(e->soft, c->nl, int)
     case PPN_F_FLAG: S(e->flag) case PPN_F_ILLEGAL: S(e->ill) case PPN_F_CASCADE_DEPTH: S(e->depth)
+    case PPN_F_ILLEGAL_COUNTS: A(e->illn, 3, int) case PPN_F_ACTION_SWITCHES: A(e->actsw, 2, int)
     case PPN_F_N_SOLVES: S(e->nsolve) case PPN_F_N_ITERS: S(e->niter) case PPN_F_CHRONIC_SLOT: S(e->slot)
     case PPN_F_CHRONIC_ROW: S(e->row) case PPN_F_N_LOADS_CUT: S(e->nlc) case PPN_F_N_PRODS_CUT: S(e->npc)
     default: return -1;

@@ -13,6 +13,17 @@ class PpnCase(C.Structure):
                 ('bus', C.POINTER(C.c_double)), ('gen', C.POINTER(C.c_double)), ('branch', C.POINTER(C.c_double))]
 
 
+REWARD_PARAM_NAMES = ['line_usage', 'distance_initial_grid', 'number_loads_cut', 'number_prods_cut', 'loadflow_exception',
+                      'illegal_broken_line_switch', 'illegal_oncooldown_line_switch',
+                      'illegal_oncooldown_substation_switch', 'too_many_productions_cut', 'too_many_consumptions_cut',
+                      'too_much_activated_elements', 'number_line_switches', 'number_node_switches']
+
+
+class PpnRewardParams(C.Structure):
+    """ppn_reward_params (include/ppn.h): coefficients of the reference's five-component reward."""
+    _fields_ = [(k, C.c_double) for k in REWARD_PARAM_NAMES]
+
+
 class PpnRules(C.Structure):
     _fields_ = [('mode', C.c_int32), ('solver', C.c_int32), ('tol', C.c_double), ('max_it', C.c_int32),
                 ('hard_overflow_coefficient', C.c_double),
@@ -39,9 +50,10 @@ class PpnChronic(C.Structure):
 FIELDS = ['VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'PRODS_NODES', 'LOADS_NODES',
           'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN',
           'SOFT_COUNT', 'DONE', 'FLAG', 'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT',
-          'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE']
+          'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE', 'REWARD', 'ILLEGAL_COUNTS',
+          'ACTION_SWITCHES']
 FIELD_ID = {k: i for i, k in enumerate(FIELDS)}
-_F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION'}
+_F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD'}
 _U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE'}
 
 
@@ -56,7 +68,7 @@ def field_dtype(name):
 
 EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limits', 'ppn_load_chronic', 'ppn_reset',
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
-           'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version']
+           'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward']
 
 
 class _Prefixed(object):
@@ -88,6 +100,9 @@ def load_library(path=None, prefix='ppn_'):
     lib.ppn_destroy.restype = C.c_int
     lib.ppn_last_error.argtypes = [vp]
     lib.ppn_last_error.restype = C.c_char_p
+    if prefix == 'ppn_':      # (the C oracle does not compute rewards: oracle/reward_np.py restates them)
+        lib.ppn_set_reward.argtypes = [vp, C.POINTER(PpnRewardParams)]
+        lib.ppn_set_reward.restype = C.c_int
     lib.ppn_set_thermal_limits.argtypes = [vp, C.POINTER(C.c_double)]
     lib.ppn_set_thermal_limits.restype = C.c_int
     lib.ppn_load_chronic.argtypes = [vp, C.c_int32, C.POINTER(PpnChronic)]

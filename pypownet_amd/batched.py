@@ -67,6 +67,13 @@ class BatchedRunEnv(object):
         done, flag, ill = self.engine.read('DONE'), self.engine.read('FLAG'), self.engine.read('ILLEGAL')
         return (self.engine.observations() if want_obs else None), done.astype(bool), flag, ill
 
+    def rewards(self, do_sum=True, simulation=False):
+        """Reward of the last step of every environment, computed on the device with the reference's shipped
+        five-component formula (coefficients: Engine.set_reward; default = default14's scaled by the number of
+        substations, which is what default118 ships): [batch] sums or [batch x 5] components."""
+        r = self.engine.read('REWARD', simulation=simulation)
+        return r.sum(axis=1) if do_sum else r
+
     def simulate(self, actions):
         self.engine.simulate(actions)
         e = self.engine

@@ -101,6 +101,7 @@ struct DevRules {
   int n_line_cooldown, n_node_cooldown;
   int max_subs, max_lines, max_total;
   int hard_mode;
+  double rw[13];     // ppn_reward_params, in declaration order
 };
 
 // Static (shared by all environments) + chronic tensors.  All pointers are device pointers.
@@ -149,6 +150,8 @@ struct DevState {
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
   long long* prof;                 // [32] cycle counters per phase (only written by -DPPN_PROF builds)
+  double* reward;                  // [5] reward components of the last step
+  int *illn, *actsw;               // [3] illegal-action counts, [2] node / line switches of the action after the step
   float* prio;                     // expected cost of the NEXT step (largest ampere flow / limit after this one): launch order
   // per-environment solve workspace (L2-resident, streamed sequentially by the numeric phases)
   u64 *ws_tri, *ws_pair;           // [TCAP], [MCAP] update triples / (pivot, neighbour) pairs with entry indices

@@ -339,6 +339,7 @@ static int alloc_state(ppn_engine* e, DevState* s) {
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
   s->prof = dalloc<long long>(e, B * 32);
   s->prio = dalloc<float>(e, B);
+  s->reward = dalloc<double>(e, B * 5); s->illn = dalloc<int>(e, B * 3); s->actsw = dalloc<int>(e, B * 2);
   s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
   s->ws_piv = dalloc<unsigned>(e, B * d.NB);
   s->ws_cache = dalloc<u8>(e, B * (size_t)d.cache_stride);   // zero-filled: header.valid == 0
@@ -387,6 +388,9 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
     case PPN_F_N_PRODS_CUT: FI(npc, int, 1, false)
     case PPN_F_SUCCESS: FI(succ, u8, 1, false)
     case PPN_F_BUS_TYPE: FI(btype, u8, d.nrows, false)
+    case PPN_F_REWARD: FI(reward, double, 5, false)
+    case PPN_F_ILLEGAL_COUNTS: FI(illn, int, 3, false)
+    case PPN_F_ACTION_SWITCHES: FI(actsw, int, 2, false)
     default: return false;
   }
 #undef FI
@@ -411,6 +415,7 @@ extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
   }
 }
 
+static void default_reward(double* rw, double c);
 extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, int32_t device, ppn_engine** out) {
   if (!c || !r || !out || batch <= 0) return fail(nullptr, PPN_E_INVALID, "ppn_create: null argument or batch <= 0");
   if (c->n_bus_rows <= 0 || (c->n_bus_rows & 1) || c->bus_cols < 10 || c->gen_cols < 8 || c->branch_cols < 11)
@@ -641,6 +646,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   R.n_node_cooldown = r->n_timesteps_actionned_node_reactionable;
   R.max_subs = r->max_number_actionned_substations; R.max_lines = r->max_number_actionned_lines;
   R.max_total = r->max_number_actionned_total; R.hard_mode = r->game_over_mode_hard;
+  default_reward(R.rw, (double)nS);
   if (R.solver != PPN_SOLVER_NEWTON && R.solver != PPN_SOLVER_FDXB) return bad("solver must be NEWTON or FDXB");
   if (R.max_it <= 0) R.max_it = (R.solver == PPN_SOLVER_NEWTON) ? 10 : 25;
   if (!(R.tol > 0)) R.tol = 1e-6;
@@ -786,6 +792,18 @@ static int copy_state(ppn_engine* e, DevState* dst, const DevState* src) {
   CP(npc, int, 1) CP(epoch, int, 1)
 #undef CP
   return rc;
+}
+
+static void default_reward(double* rw, double c) {   // parameters/default14/reward_signal.py:8-43 with `constant` = c
+  rw[0] = -1.0; rw[1] = -0.02; rw[2] = -c / 5.0; rw[3] = -c / 10.0; rw[4] = -c;
+  rw[5] = rw[6] = rw[7] = -c / 100.0; rw[8] = -c; rw[9] = -c; rw[10] = -5.0 * c; rw[11] = -0.2; rw[12] = -0.1;
+}
+
+extern "C" int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p) {
+  if (!e || !p) return PPN_E_INVALID;
+  const double* v = (const double*)p;
+  for (int k = 0; k < 13; ++k) e->dc.R.rw[k] = v[k];
+  return PPN_OK;
 }
 
 extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,

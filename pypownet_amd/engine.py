@@ -118,6 +118,14 @@ class Engine(object):
         self.thermal_limits = a
         self._check(self._lib.ppn_set_thermal_limits(self._h, a.ctypes.data_as(C.POINTER(C.c_double))), 'ppn_set_thermal_limits')
 
+    def set_reward(self, params):
+        """Coefficients of the device-side reward (PPN_F_REWARD): a dict with the keys of ``_lib.REWARD_PARAM_NAMES`` or a
+        ``reward_signal.DefaultGridRewardSignal`` (the reference's shipped CustomRewardSignal)."""
+        if hasattr(params, 'as_engine_params'):
+            params = params.as_engine_params()
+        p = _lib.PpnRewardParams(**{k: float(params[k]) for k in _lib.REWARD_PARAM_NAMES})
+        self._check(self._lib.ppn_set_reward(self._h, C.byref(p)), 'ppn_set_reward')
+
     def load_chronic(self, ch):
         """Upload a pypownet_amd.chronic.Chronic into the next slot."""
         T = ch.n_timesteps

@@ -26,6 +26,18 @@ class DefaultGridRewardSignal(RewardSignal):
         self.too_much_activated_elements = -5 * c
         self.k_line_switch, self.k_node_switch = -.2, -.1
 
+    def as_engine_params(self):
+        """The same coefficients in the layout of ``ppn_reward_params`` (include/ppn.h): Engine.set_reward."""
+        return {'line_usage': self.k_line_usage, 'distance_initial_grid': self.k_distance,
+                'number_loads_cut': self.k_loads_cut, 'number_prods_cut': self.k_prods_cut,
+                'loadflow_exception': self.loadflow_exception_reward,
+                'illegal_broken_line_switch': self.k_illegal, 'illegal_oncooldown_line_switch': self.k_illegal,
+                'illegal_oncooldown_substation_switch': self.k_illegal,
+                'too_many_productions_cut': self.too_many_productions_cut,
+                'too_many_consumptions_cut': self.too_many_consumptions_cut,
+                'too_much_activated_elements': self.too_much_activated_elements,
+                'number_line_switches': self.k_line_switch, 'number_node_switches': self.k_node_switch}
+
     def _action_cost(self, action):
         import numpy as np
         return self.k_node_switch * float(np.sum(action.get_node_splitting_subaction())) + \

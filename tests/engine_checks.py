@@ -271,3 +271,56 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
     stats['dropped'] = int((~tracked).sum())
     assert stats['dropped'] <= max(2, batch // 10), 'too many environments dropped as degenerate: %d' % stats['dropped']
     return stats
+
+
+def check_device_reward(lib_path, envname, steps, batch, seed=4321):
+    """PPN_F_REWARD (game_reward on the device) against oracle/reward_np.py evaluated on the C ORACLE's state and flags,
+    in lock-step under random actions (illegal actions, game overs and the fused restart included).  The usage term is a
+    sum of ~nl squares in a different order: relative tolerance 1e-12."""
+    import os
+    from helpers import ROOT
+    from pypownet_amd.engine import Engine
+    from oracle import reward_np
+    case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path)
+    orc = Engine(case, cfg, batch, chronics=chronics, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
+                 _lib_prefix='orc_')
+    k = reward_np.coefficients(case.nS)       # what ppn_create installs (default14: 14, default118: 118)
+    rng = np.random.default_rng(seed)
+    eng.reset()
+    orc.reset()
+    limits = orc.thermal_limits
+    tracked = np.ones(batch, dtype=bool)
+    seen = dict(ok=0, illegal=0, too_many=0, diverged=0, cut=0)
+    for t in range(steps):
+        acts = random_actions(case, rng, batch, p_node=0.7, p_line=0.5)
+        if t % 3 == 2:      # some actions beyond the activation maxima
+            acts[: max(4, batch // 4), case.ntopo_offset_lines: case.ntopo_offset_lines + min(60, case.nl)] = 1
+        eng.step(acts, auto_reset=False)
+        orc.step(acts, auto_reset=False)
+        min_vm = np.zeros(batch)
+        assert orc._lib._lib.orc_debug_min_vm(orc._h, min_vm.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        tracked &= ~(min_vm < 1e-6)
+        assert np.array_equal(eng.read('FLAG')[tracked], orc.read('FLAG')[tracked])
+        assert np.array_equal(eng.read('ILLEGAL_COUNTS')[tracked], orc.read('ILLEGAL_COUNTS')[tracked])
+        assert np.array_equal(eng.read('ACTION_SWITCHES')[tracked], orc.read('ACTION_SWITCHES')[tracked])
+        flag, ill, illn, sw = orc.read('FLAG'), orc.read('ILLEGAL'), orc.read('ILLEGAL_COUNTS'), orc.read('ACTION_SWITCHES')
+        nlc, npc, amps = orc.read('N_LOADS_CUT'), orc.read('N_PRODS_CUT'), orc.read('AMPS')
+        topo = np.concatenate([orc.read('PRODS_NODES'), orc.read('LOADS_NODES'), orc.read('LINES_OR_NODES'),
+                               orc.read('LINES_EX_NODES')], axis=1)
+        dev = eng.read('REWARD')
+        for e in np.where(tracked)[0]:
+            ref = reward_np.compute_reward(k, int(flag[e]), int(ill[e]), illn[e], int(sw[e, 0]), int(sw[e, 1]), int(nlc[e]),
+                                           int(npc[e]), topo[e], amps[e], limits)
+            np.testing.assert_allclose(dev[e], ref, rtol=1e-12, atol=1e-12, err_msg='step %d env %d' % (t, e))
+            seen['ok'] += int(flag[e] == 0 and ill[e] == 0)
+            seen['illegal'] += int(flag[e] == 0 and ill[e] != 0 and not ill[e] & 1)
+            seen['too_many'] += int(flag[e] == 0 and bool(ill[e] & 1))
+            seen['diverged'] += int(flag[e] == 1)
+            seen['cut'] += int(flag[e] in (2, 3))
+        eng.process_game_over()
+        orc.process_game_over()
+    assert seen['ok'] and seen['illegal'] and seen['too_many'] and seen['diverged'], seen
+    return seen
+

@@ -79,3 +79,9 @@ def test_emu_random_actions_vs_c_oracle(emu_lib, env, solver, steps, batch):
     subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
     st = ec.check_random_actions_vs_c_oracle(emu_lib, env, steps, batch, solver)
     assert st['split_buses'] > 0
+
+
+@pytest.mark.parametrize('env,steps,batch', [('default14_for_tests_alpha', 40, 32), ('default118', 9, 24)])
+def test_emu_device_reward_matches_restatement(emu_lib, env, steps, batch):
+    seen = ec.check_device_reward(emu_lib, env, steps, batch)
+    assert seen['ok'] > 0

@@ -91,3 +91,8 @@ def test_gpu_launch_order_does_not_change_results(monkeypatch):
     for f in states[0]:
         assert np.array_equal(states[0][f], states[1][f], equal_nan=True), f
     assert int(states[0]['N_SOLVES'].sum()) > 8 * B      # cascades did happen
+
+
+@pytest.mark.parametrize('env,steps,batch', [('default14_for_tests_alpha', 60, 64), ('default118', 12, 64)])
+def test_gpu_device_reward_matches_restatement(env, steps, batch):
+    ec.check_device_reward(HIP, env, steps, batch)

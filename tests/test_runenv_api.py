@@ -105,3 +105,33 @@ def test_default_reward_signal(emu_lib):
     assert len(r) == 5 and r[0] == 0 and r[1] == 0 and r[2] == 0 and r[3] == 0 and r[4] < 0
     o = env.observation_space.array_to_observation(obs)
     assert abs(r[4] + np.sum(np.square(o.ampere_flows / o.thermal_limits))) < 1e-12
+
+
+def test_device_reward_equals_host_reward_signal(emu_lib):
+    """The reward computed inside the step kernel (PPN_F_REWARD) equals what RunEnv.step returns when it evaluates the
+    shipped five-component reward class on the Observation object (the reference's path, environment.py:866-874) -- for
+    legal, illegal (repaired in place) and wholly rejected actions, for step and simulate."""
+    from pypownet_amd.reward_signal import DefaultGridRewardSignal
+    env = make_env(emu_lib, 'default14_for_tests')
+    env.reward_signal = DefaultGridRewardSignal(14)
+    sp = env.action_space
+    rng = np.random.default_rng(7)
+    kinds = set()
+    for t in range(40):
+        a = sp.get_do_nothing_action()
+        if t % 2:
+            sub = int(rng.choice(sp.substations_ids))
+            n = sp.get_number_elements_of_substation(sub)
+            sp.set_substation_switches_in_action(a, sub, rng.integers(0, 2, size=n))
+        if t % 3 == 0:
+            a[len(a) - env.game.case.nl + int(rng.integers(env.game.case.nl))] = 1     # a line-status switch
+        if t % 7 == 6:
+            a[-8:] = 1                      # beyond max_number_actionned_lines
+        _, rs, _, _ = env.simulate(np.array(a), do_sum=False)
+        np.testing.assert_allclose(env.game.engine.read('REWARD', simulation=True)[0], rs, rtol=1e-12, atol=1e-12)
+        obs, r, done, flag = env.step(np.array(a), do_sum=False)
+        np.testing.assert_allclose(env.game.engine.read('REWARD')[0], r, rtol=1e-12, atol=1e-12)
+        kinds.add(type(flag).__name__)
+        if done:
+            env.process_game_over()
+    assert 'IllegalActionException' in kinds and 'NoneType' in kinds, kinds
