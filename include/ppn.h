@@ -204,6 +204,13 @@ int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* c
  * in the same call; PPN_F_DONE/FLAG still report the step's outcome. */
 int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
              int32_t auto_reset);
+/* Topology-action search (the reference's search agents call RunEnv.simulate once per candidate,
+ * pypownet/agent.py:161-325): candidate c forks the CURRENT state of environment env_ids[c] and plays
+ * Game.simulate(actions[c]) on it (game.py:887-943); any number of candidates per environment, one kernel launch.
+ * actions: u8 [n x action_len] (host or device), env_ids: host int32 [n].  Results are read with
+ * ppn_read(..., from_simulation = 2): n rows per field, in candidate order (PPN_F_REWARD, PPN_F_FLAG, PPN_F_OBSERVATION...). */
+int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, const int32_t* env_ids,
+                            int32_t n);
 /* Game.process_game_over for every environment whose done flag is set (game.py:762-797).  env_mask (host,
  * u8[batch], may be NULL) additionally forces the listed LIVE environments through it, as a caller of
  * RunEnv.process_game_over() may do at any time (reference tests/common_assets.py:51). */

@@ -67,6 +67,21 @@ class BatchedRunEnv(object):
         done, flag, ill = self.engine.read('DONE'), self.engine.read('FLAG'), self.engine.read('ILLEGAL')
         return (self.engine.observations() if want_obs else None), done.astype(bool), flag, ill
 
+    def search(self, candidate_actions, want_obs=False):
+        """Topology-action search (what the reference's search agents do with one ``simulate`` call per candidate,
+        pypownet/agent.py:161-325): ``candidate_actions`` uint8 [batch x K x action_length]; every candidate is
+        simulated from the current state of its environment in one launch.  Returns (rewards [batch x K], done
+        [batch x K], flag [batch x K], obs [batch x K x observation_length] | None)."""
+        a = np.ascontiguousarray(candidate_actions, dtype=np.uint8)
+        B, K = a.shape[0], a.shape[1]
+        assert B == self.batch and a.shape[2] == self.action_length
+        env_ids = np.repeat(np.arange(B, dtype=np.int32), K)
+        e = self.engine
+        e.simulate_candidates(a.reshape(B * K, -1), env_ids)
+        obs = e.observations(simulation=2).reshape(B, K, -1) if want_obs else None
+        return (e.read('REWARD', simulation=2).sum(axis=1).reshape(B, K), e.read('DONE', simulation=2).astype(bool).reshape(B, K),
+                e.read('FLAG', simulation=2).reshape(B, K), obs)
+
     def rewards(self, do_sum=True, simulation=False):
         """Reward of the last step of every environment, computed on the device with the reference's shipped
         five-component formula (coefficients: Engine.set_reward; default = default14's scaled by the number of

@@ -63,6 +63,9 @@ struct ppn_engine {
   int batch = 0, device = 0, W = 1;
   DevCase dc;
   DevState st, sim;
+  DevState cand;              // forked states of ppn_simulate_candidates (capacity cand_cap rows)
+  int cand_cap = 0, n_cand = 0;
+  u8* d_cand_actions = nullptr; double* d_cand_obs = nullptr; int* d_cand_ids = nullptr;
   std::vector<void*> allocs;
   std::vector<HostChronic> chronics;
   bool chronics_dirty = true;
@@ -320,9 +323,8 @@ extern "C" int ppn_destroy(ppn_engine* e) {
   return PPN_OK;
 }
 
-static int alloc_state(ppn_engine* e, DevState* s) {
+static int alloc_state(ppn_engine* e, DevState* s, size_t B) {
   const DevCase& d = e->dc;
-  const size_t B = e->batch;
   s->vm = dalloc<double>(e, B * d.nrows); s->va = dalloc<double>(e, B * d.nrows);
   s->pg = dalloc<double>(e, B * d.nP); s->qg = dalloc<double>(e, B * d.nP); s->vg = dalloc<double>(e, B * d.nP);
   s->pd = dalloc<double>(e, B * d.nL); s->qd = dalloc<double>(e, B * d.nL);
@@ -651,7 +653,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (R.max_it <= 0) R.max_it = (R.solver == PPN_SOLVER_NEWTON) ? 10 : 25;
   if (!(R.tol > 0)) R.tol = 1e-6;
 
-  if (alloc_state(e, &e->st) || alloc_state(e, &e->sim)) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
+  if (alloc_state(e, &e->st, (size_t)batch) || alloc_state(e, &e->sim, (size_t)batch)) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
   e->d_actions = dalloc<u8>(e, (size_t)batch * d.alen);
   e->d_valid = dalloc<u8>(e, batch);
   e->d_perm = dalloc<int>(e, batch);
@@ -836,6 +838,75 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
   return PPN_OK;
 }
 
+// ---- topology-action search: K candidate actions evaluated from the current state of chosen environments --------------
+#ifndef PPN_EMU
+__global__ void __launch_bounds__(256) ppn_gather_rows(unsigned char* dst, const unsigned char* src, const int* idx,
+                                                       size_t row_bytes) {
+  const unsigned char* s = src + (size_t)idx[blockIdx.x] * row_bytes;
+  unsigned char* d = dst + (size_t)blockIdx.x * row_bytes;
+  if (((row_bytes | (size_t)s | (size_t)d) & 15) == 0) {
+    for (size_t k = threadIdx.x; k < row_bytes / 16; k += 256) ((uint4*)d)[k] = ((const uint4*)s)[k];
+  } else {
+    for (size_t k = threadIdx.x; k < row_bytes; k += 256) d[k] = s[k];
+  }
+}
+#endif
+static int gather_rows(ppn_engine* e, void* dst, const void* src, const int* d_idx, const int* h_idx, size_t row_bytes, int n) {
+#ifdef PPN_EMU
+  (void)e; (void)d_idx;
+  for (int c = 0; c < n; ++c) memcpy((char*)dst + (size_t)c * row_bytes, (const char*)src + (size_t)h_idx[c] * row_bytes, row_bytes);
+  return 0;
+#else
+  (void)h_idx;
+  hipLaunchKernelGGL(ppn_gather_rows, dim3(n), dim3(256), 0, e->stream, (unsigned char*)dst, (const unsigned char*)src, d_idx, row_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+#endif
+}
+
+extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device,
+                                       const int32_t* env_ids, int32_t n) {
+  if (!e || !actions || !env_ids || n <= 0) return PPN_E_INVALID;
+  for (int c = 0; c < n; ++c) if (env_ids[c] < 0 || env_ids[c] >= e->batch) return fail(e, PPN_E_INVALID, "ppn_simulate_candidates: environment %d out of range", env_ids[c]);
+  if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
+  const DevCase& d = e->dc;
+  if (n > e->cand_cap) {      // (re)allocate the candidate slots; earlier slots are released with the engine
+    const int cap = std::max(n, std::max(e->batch, 2 * e->cand_cap));
+    if (alloc_state(e, &e->cand, (size_t)cap)) return fail(e, PPN_E_HIP, "candidate slots: device allocation failed: %s", dev_err());
+    e->d_cand_actions = dalloc<u8>(e, (size_t)cap * d.alen);
+    e->d_cand_obs = dalloc<double>(e, (size_t)cap * d.obslen);
+    e->d_cand_ids = dalloc<int>(e, (size_t)cap);
+    if (!e->d_cand_actions || !e->d_cand_obs || !e->d_cand_ids) return fail(e, PPN_E_HIP, "candidate slots: device allocation failed");
+    e->cand_cap = cap;
+  }
+  e->n_cand = n;
+  if (dev_h2d(e->d_cand_ids, env_ids, sizeof(int) * (size_t)n, e->stream)) return fail(e, PPN_E_HIP, "candidate ids upload failed");
+  const u8* dact = actions;
+  if (!actions_on_device) {
+    if (dev_h2d(e->d_cand_actions, actions, (size_t)n * d.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
+    dact = e->d_cand_actions;
+  }
+  // fork: every per-environment array of the live state, plus the schedule cache and its records (a candidate that does
+  // not move an element to another busbar solves on the schedule its environment already has)
+  int rc = 0;
+  DevState* dst = &e->cand; const DevState* src = &e->st;
+#define GR(m, type, cnt) rc |= gather_rows(e, dst->m, src->m, e->d_cand_ids, env_ids, sizeof(type) * (size_t)(cnt), n);
+  GR(vm, double, d.nrows) GR(va, double, d.nrows) GR(pg, double, d.nP) GR(qg, double, d.nP) GR(vg, double, d.nP)
+  GR(pd, double, d.nL) GR(qd, double, d.nL) GR(pf, double, d.nl) GR(qf, double, d.nl) GR(pt, double, d.nl)
+  GR(qt, double, d.nl) GR(amps, double, d.nl) GR(pn, u8, d.nP) GR(ln, u8, d.nL) GR(on, u8, d.nl) GR(en, u8, d.nl)
+  GR(st, u8, d.nl) GR(rec, int, d.nl) GR(lcd, int, d.nl) GR(ncd, int, d.nS) GR(soft, int, d.nl)
+  GR(done, u8, 1) GR(dead, u8, 1) GR(succ, u8, 1) GR(btype, u8, d.nrows) GR(flag, int, 1) GR(ill, int, 1)
+  GR(depth, int, 1) GR(nsolve, int, 1) GR(niter, int, 1) GR(slot, int, 1) GR(row, int, 1) GR(nlc, int, 1)
+  GR(npc, int, 1) GR(epoch, int, 1)
+  GR(ws_tri, u64, d.TCAP) GR(ws_pair, u64, d.MCAP) GR(ws_piv, unsigned, d.NB) GR(ws_cache, u8, d.cache_stride)
+#undef GR
+  if (rc) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err());
+  KArgs a = make_args(e, false);
+  a.st = e->cand;
+  a.actions = dact; a.sim = 1; a.auto_reset = 0;
+  if (launch<K_STEP>(e, a, n)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  return PPN_OK;
+}
+
 extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
   if (!e) return PPN_E_INVALID;
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
@@ -899,16 +970,19 @@ extern "C" int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, i
 
 extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation) {
   if (!e || !dst) return PPN_E_INVALID;
-  const DevState& s = from_simulation ? e->sim : e->st;
-  const size_t B = e->batch;
+  if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read: no candidates have been simulated");
+  const DevState& s = (from_simulation == 2) ? e->cand : (from_simulation ? e->sim : e->st);
+  const size_t B = (from_simulation == 2) ? (size_t)e->n_cand : (size_t)e->batch;
   if (f == PPN_F_OBSERVATION) {
     const size_t need = B * e->dc.obslen * sizeof(double);
     if (bytes < need) return fail(e, PPN_E_INVALID, "ppn_read: buffer too small (%zu < %zu)", bytes, need);
     if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
     KArgs a = make_args(e, from_simulation != 0);
-    a.obs = to_host ? e->d_obs : (double*)dst;
-    if (launch<K_OBS>(e, a, e->batch)) return fail(e, PPN_E_HIP, "observation kernel launch failed: %s", dev_err());
-    if (to_host && dev_d2h(dst, e->d_obs, need, e->stream)) return fail(e, PPN_E_HIP, "download failed: %s", dev_err());
+    a.st = s;
+    double* stage = (from_simulation == 2) ? e->d_cand_obs : e->d_obs;
+    a.obs = to_host ? stage : (double*)dst;
+    if (launch<K_OBS>(e, a, (int)B)) return fail(e, PPN_E_HIP, "observation kernel launch failed: %s", dev_err());
+    if (to_host && dev_d2h(dst, stage, need, e->stream)) return fail(e, PPN_E_HIP, "download failed: %s", dev_err());
     return PPN_OK;
   }
   FieldInfo fi; bool w;

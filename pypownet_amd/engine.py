@@ -61,6 +61,7 @@ class Engine(object):
         self._lib = _lib.load_library(_lib_path, _lib_prefix)
         self.case = case if isinstance(case, Case) else Case(case)
         self.batch = int(batch)
+        self._n_candidates = 0
         ppc = self.case.ppc
         self._bus = np.ascontiguousarray(ppc['bus'], dtype=np.float64)
         self._gen = np.ascontiguousarray(ppc['gen'], dtype=np.float64)
@@ -183,6 +184,17 @@ class Engine(object):
         a = self._actions(actions)
         self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 1, 0), 'ppn_step(simulate)')
 
+    def simulate_candidates(self, actions, env_ids):
+        """Topology-action search: candidate c plays ``Game.simulate(actions[c])`` from the CURRENT state of environment
+        ``env_ids[c]`` (any number of candidates per environment, one launch).  Read the outcome with
+        ``read(name, simulation=2)`` / ``observations(simulation=2)``: one row per candidate."""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        a = np.ascontiguousarray(actions, dtype=np.uint8)
+        assert a.shape == (len(ids), self.case.action_length)
+        self._n_candidates = len(ids)
+        self._check(self._lib.ppn_simulate_candidates(self._h, a.ctypes.data, 0, ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                      len(ids)), 'ppn_simulate_candidates')
+
     def process_game_over(self, env_mask=None):
         """Game.process_game_over for every dead environment, plus the live ones selected by env_mask."""
         if env_mask is None:
@@ -216,13 +228,14 @@ class Engine(object):
         fid = _lib.FIELD_ID[name]
         nbytes = int(self._lib.ppn_field_bytes(self._h, fid))
         dt = np.dtype(_lib.field_dtype(name))
-        out = np.empty((self.batch, nbytes // dt.itemsize), dtype=dt)
-        self._check(self._lib.ppn_read(self._h, fid, out.ctypes.data, out.nbytes, 1, 1 if simulation else 0), 'ppn_read')
+        rows = self._n_candidates if int(simulation) == 2 else self.batch
+        out = np.empty((rows, nbytes // dt.itemsize), dtype=dt)
+        self._check(self._lib.ppn_read(self._h, fid, out.ctypes.data, out.nbytes, 1, int(simulation)), 'ppn_read')
         return out[:, 0] if out.shape[1] == 1 and name not in ('OBSERVATION',) and nbytes == dt.itemsize else out
 
     def read_into_device(self, name, dev_ptr, nbytes, simulation=False):
         fid = _lib.FIELD_ID[name]
-        self._check(self._lib.ppn_read(self._h, fid, C.c_void_p(int(dev_ptr)), nbytes, 0, 1 if simulation else 0), 'ppn_read')
+        self._check(self._lib.ppn_read(self._h, fid, C.c_void_p(int(dev_ptr)), nbytes, 0, int(simulation)), 'ppn_read')
 
     def write(self, name, values):
         fid = _lib.FIELD_ID[name]

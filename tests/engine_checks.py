@@ -324,3 +324,56 @@ def check_device_reward(lib_path, envname, steps, batch, seed=4321):
     assert seen['ok'] and seen['illegal'] and seen['too_many'] and seen['diverged'], seen
     return seen
 
+
+def check_candidate_search(lib_path, envname, batch, n_actions, warm_steps=4, seed=99):
+    """ppn_simulate_candidates: every environment x n_actions candidate actions in ONE launch equals, candidate by candidate,
+    Game.simulate on the oracle (which replays one action per environment per call); and it leaves the live state untouched."""
+    import os
+    from helpers import ROOT
+    from pypownet_amd.engine import Engine
+    case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path)
+    orc = Engine(case, cfg, batch, chronics=chronics, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
+                 _lib_prefix='orc_')
+    rng = np.random.default_rng(seed)
+    eng.reset()
+    orc.reset()
+    act0 = np.zeros((batch, case.action_length), dtype=np.uint8)
+    for _ in range(warm_steps):
+        eng.step(act0, auto_reset=True)
+        orc.step(act0, auto_reset=True)
+    before = {f: eng.read(f).copy() for f in ('VM', 'VA', 'LINES_STATUS', 'LINES_OR_NODES', 'RECONNECTABLE', 'CHRONIC_ROW', 'N_SOLVES')}
+    cands = [random_actions(case, rng, batch, p_node=0.8, p_line=0.5) for _ in range(n_actions)]
+    cands[0][:] = 0                                                   # candidate 0: do nothing
+    acts = np.stack(cands, axis=1).reshape(batch * n_actions, -1)     # candidate c = env * n_actions + k
+    env_ids = np.repeat(np.arange(batch, dtype=np.int32), n_actions)
+    eng.simulate_candidates(acts, env_ids)
+    got = {f: eng.read(f, simulation=2) for f in ('FLAG', 'ILLEGAL', 'DONE', 'LINES_STATUS', 'PRODS_NODES', 'LINES_OR_NODES',
+                                                   'LINES_EX_NODES', 'AMPS', 'VM', 'BUS_TYPE', 'CASCADE_DEPTH')}
+    obs = eng.observations(simulation=2)
+    assert obs.shape == (batch * n_actions, case.observation_length)
+    live = eng.read('DONE') == 0
+    n_checked = 0
+    for k in range(n_actions):
+        orc.simulate(cands[k])
+        sel = np.arange(batch) * n_actions + k
+        min_vm = np.zeros(batch)       # (diagnostic of the last orc step; simulate does not refresh it: use VM of the result)
+        ok = live.copy()
+        vm_o, bt_o = orc.read('VM', simulation=True), orc.read('BUS_TYPE', simulation=True)
+        ok &= ~(((vm_o < 1e-6) & (bt_o != 4)).any(axis=1))
+        for f in ('FLAG', 'ILLEGAL', 'DONE', 'LINES_STATUS', 'PRODS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'CASCADE_DEPTH'):
+            a, b = got[f][sel][ok], orc.read(f, simulation=True)[ok]
+            assert np.array_equal(a, b), '%s differs for action %d' % (f, k)
+        good = ok & (orc.read('FLAG', simulation=True) == 0)
+        np.testing.assert_allclose(got['AMPS'][sel][good], orc.read('AMPS', simulation=True)[good], rtol=0, atol=1e-5)
+        lv = (bt_o != 4) & good[:, None]
+        np.testing.assert_allclose(got['VM'][sel][lv], vm_o[lv], rtol=0, atol=1e-8)
+        eng.simulate(cands[k])        # the engine's own one-action-per-environment simulate: same observation rows
+        assert np.array_equal(obs[sel][live], eng.observations(simulation=True)[live], equal_nan=True)
+        n_checked += int(good.sum())
+    for f, v in before.items():
+        assert np.array_equal(eng.read(f), v), 'candidate search changed the live %s' % f
+    assert n_checked > batch      # plenty of successful candidates were compared
+    return n_checked
+

@@ -85,3 +85,8 @@ def test_emu_random_actions_vs_c_oracle(emu_lib, env, solver, steps, batch):
 def test_emu_device_reward_matches_restatement(emu_lib, env, steps, batch):
     seen = ec.check_device_reward(emu_lib, env, steps, batch)
     assert seen['ok'] > 0
+
+
+@pytest.mark.parametrize('env,batch,k', [('default14_for_tests_alpha', 12, 5), ('default118', 6, 3)])
+def test_emu_candidate_search_equals_simulate(emu_lib, env, batch, k):
+    ec.check_candidate_search(emu_lib, env, batch, k)

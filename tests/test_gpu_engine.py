@@ -96,3 +96,8 @@ def test_gpu_launch_order_does_not_change_results(monkeypatch):
 @pytest.mark.parametrize('env,steps,batch', [('default14_for_tests_alpha', 60, 64), ('default118', 12, 64)])
 def test_gpu_device_reward_matches_restatement(env, steps, batch):
     ec.check_device_reward(HIP, env, steps, batch)
+
+
+@pytest.mark.parametrize('env,batch,k', [('default14_for_tests_alpha', 48, 8), ('default118', 32, 6)])
+def test_gpu_candidate_search_equals_simulate(env, batch, k):
+    ec.check_candidate_search(HIP, env, batch, k)
