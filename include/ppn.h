@@ -224,7 +224,14 @@ int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_t* valid);
 int ppn_runpf_batch(ppn_engine* e);
 
 /* ---- state access ---------------------------------------------------------------------------------- */
-size_t ppn_field_bytes(const ppn_engine* e, ppn_field f);      /* bytes of one environment's field */
+size_t ppn_field_bytes(const ppn_engine* e, ppn_field f);      /* Observation layouts of the reference (environment.py:406-531): layout 0 = Observation.as_array() (PPN_F_OBSERVATION),
+ * 1 = MinimalistObservation.as_array(), 2 = MinimalistACObservation.as_array() -- both prefixes of the full array, gathered
+ * directly at their own row stride; as_f32 != 0 emits float32 instead of float64 (3-4x fewer bytes
+ * to move for policies that need no more).  dst: [rows x ppn_observation_length(layout)], rows as in ppn_read. */
+int ppn_read_observation(ppn_engine* e, int32_t layout, int32_t as_f32, void* dst, size_t bytes, int32_t to_host,
+                         int32_t from_simulation);
+int32_t ppn_observation_length(const ppn_engine* e, int32_t layout);
+/* bytes of one environment's field */
 int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation);
 int ppn_write(ppn_engine* e, ppn_field f, const void* src, size_t bytes);   /* whole batch, host pointer */
 int ppn_sync(ppn_engine* e);

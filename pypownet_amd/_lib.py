@@ -69,7 +69,7 @@ def field_dtype(name):
 EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limits', 'ppn_load_chronic', 'ppn_reset',
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
-           'ppn_simulate_candidates']
+           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length']
 
 
 class _Prefixed(object):
@@ -106,6 +106,10 @@ def load_library(path=None, prefix='ppn_'):
         lib.ppn_set_reward.restype = C.c_int
         lib.ppn_simulate_candidates.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
         lib.ppn_simulate_candidates.restype = C.c_int
+        lib.ppn_read_observation.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_size_t, C.c_int32, C.c_int32]
+        lib.ppn_read_observation.restype = C.c_int
+        lib.ppn_observation_length.argtypes = [vp, C.c_int32]
+        lib.ppn_observation_length.restype = C.c_int32
     lib.ppn_set_thermal_limits.argtypes = [vp, C.POINTER(C.c_double)]
     lib.ppn_set_thermal_limits.restype = C.c_int
     lib.ppn_load_chronic.argtypes = [vp, C.c_int32, C.POINTER(PpnChronic)]

@@ -131,7 +131,8 @@ struct KArgs {
   const u8* actions;
   u8* valid;
   const int *ids, *slots, *t0;
-  double* obs;
+  void* obs;            // K_OBS output: double or float rows of obs_stride elements
+  int obs_sections, obs_stride, obs_f32;   // 1 minimalist, 2 + AC extras, 3 full observation
   int sim, auto_reset;
   const int* perm;      // launch order of the step kernel: workgroup b runs environment perm[b] (null: b)
 };
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPN_WAV
   else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, lane0);
   else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, lane0);
   else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, lane0);
-  else if (KIND == K_OBS) body_obs(a.d, a.st, S, a.obs, env, lane0);
+  else if (KIND == K_OBS) { if (a.obs_f32) body_obs<float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, lane0); else body_obs<double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, lane0); }
 }
 #endif
 
@@ -198,7 +199,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, 0);
     else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, 0);
-    else if (KIND == K_OBS) body_obs(a.d, a.st, S, a.obs, env, 0);
+    else if (KIND == K_OBS) { if (a.obs_f32) body_obs<float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0); }
   }
   if (timed) e->launches++;
   return 0;
@@ -968,23 +969,41 @@ extern "C" int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, i
   return PPN_OK;
 }
 
+static int obs_length(const DevCase& d, int layout) {     // environment.py:406-531
+  const int mini = 4 * d.nL + 4 * d.nP + 6 * d.nl + d.nS + d.nl + 6;
+  const int ac = mini + 3 * d.nL + 3 * d.nP + 6 * d.nl;
+  return layout == 1 ? mini : (layout == 2 ? ac : d.obslen);
+}
+
+extern "C" int ppn_read_observation(ppn_engine* e, int32_t layout, int32_t as_f32, void* dst, size_t bytes, int32_t to_host,
+                                    int32_t from_simulation) {
+  if (!e || !dst || layout < 0 || layout > 2) return PPN_E_INVALID;
+  if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read_observation: no candidates have been simulated");
+  const size_t B = (from_simulation == 2) ? (size_t)e->n_cand : (size_t)e->batch;
+  const int len = obs_length(e->dc, layout);
+  const size_t need = B * (size_t)len * (as_f32 ? sizeof(float) : sizeof(double));
+  if (bytes < need) return fail(e, PPN_E_INVALID, "ppn_read_observation: buffer too small (%zu < %zu)", bytes, need);
+  if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
+  KArgs a = make_args(e, from_simulation != 0);
+  a.st = (from_simulation == 2) ? e->cand : (from_simulation ? e->sim : e->st);
+  void* stage = (from_simulation == 2) ? (void*)e->d_cand_obs : (void*)e->d_obs;     // sized for the full f64 layout
+  a.obs = to_host ? stage : dst;
+  a.obs_sections = layout == 0 ? 3 : layout; a.obs_stride = len; a.obs_f32 = as_f32 ? 1 : 0;
+  if (launch<K_OBS>(e, a, (int)B)) return fail(e, PPN_E_HIP, "observation kernel launch failed: %s", dev_err());
+  if (to_host && dev_d2h(dst, stage, need, e->stream)) return fail(e, PPN_E_HIP, "download failed: %s", dev_err());
+  return PPN_OK;
+}
+
+extern "C" int32_t ppn_observation_length(const ppn_engine* e, int32_t layout) {
+  return (!e || layout < 0 || layout > 2) ? -1 : obs_length(e->dc, layout);
+}
+
 extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation) {
   if (!e || !dst) return PPN_E_INVALID;
   if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read: no candidates have been simulated");
   const DevState& s = (from_simulation == 2) ? e->cand : (from_simulation ? e->sim : e->st);
   const size_t B = (from_simulation == 2) ? (size_t)e->n_cand : (size_t)e->batch;
-  if (f == PPN_F_OBSERVATION) {
-    const size_t need = B * e->dc.obslen * sizeof(double);
-    if (bytes < need) return fail(e, PPN_E_INVALID, "ppn_read: buffer too small (%zu < %zu)", bytes, need);
-    if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
-    KArgs a = make_args(e, from_simulation != 0);
-    a.st = s;
-    double* stage = (from_simulation == 2) ? e->d_cand_obs : e->d_obs;
-    a.obs = to_host ? stage : (double*)dst;
-    if (launch<K_OBS>(e, a, (int)B)) return fail(e, PPN_E_HIP, "observation kernel launch failed: %s", dev_err());
-    if (to_host && dev_d2h(dst, stage, need, e->stream)) return fail(e, PPN_E_HIP, "download failed: %s", dev_err());
-    return PPN_OK;
-  }
+  if (f == PPN_F_OBSERVATION) return ppn_read_observation(e, 0, 0, dst, bytes, to_host, from_simulation);
   FieldInfo fi; bool w;
   if (!field_info(e, f, &fi, &w)) return fail(e, PPN_E_INVALID, "ppn_read: unknown field %d", (int)f);
   const size_t need = fi.elem * fi.n * B;

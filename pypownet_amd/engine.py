@@ -243,5 +243,19 @@ class Engine(object):
         a = np.ascontiguousarray(values, dtype=dt)
         self._check(self._lib.ppn_write(self._h, fid, a.ctypes.data, a.nbytes), 'ppn_write')
 
-    def observations(self, simulation=False):
-        return self.read('OBSERVATION', simulation=simulation)
+    OBS_LAYOUTS = {'full': 0, 'minimalist': 1, 'ac_minimalist': 2}
+
+    def observations(self, simulation=False, layout='full', dtype=np.float64):
+        """``Observation.as_array()`` of every environment (layout 'full'), or the reference's reduced layouts
+        ``as_minimalist().as_array()`` / ``as_ac_minimalist().as_array()`` gathered directly on the device;
+        dtype float64 (reference) or float32."""
+        if layout == 'full' and np.dtype(dtype) == np.float64:
+            return self.read('OBSERVATION', simulation=simulation)
+        lay = self.OBS_LAYOUTS[layout]
+        n = int(self._lib.ppn_observation_length(self._h, lay))
+        rows = self._n_candidates if int(simulation) == 2 else self.batch
+        out = np.empty((rows, n), dtype=np.dtype(dtype))
+        assert out.dtype in (np.float32, np.float64)
+        self._check(self._lib.ppn_read_observation(self._h, lay, 1 if out.dtype == np.float32 else 0, out.ctypes.data,
+                                                   out.nbytes, 1, int(simulation)), 'ppn_read_observation')
+        return out

@@ -101,3 +101,21 @@ def test_gpu_device_reward_matches_restatement(env, steps, batch):
 @pytest.mark.parametrize('env,batch,k', [('default14_for_tests_alpha', 48, 8), ('default118', 32, 6)])
 def test_gpu_candidate_search_equals_simulate(env, batch, k):
     ec.check_candidate_search(HIP, env, batch, k)
+
+
+def test_gpu_reduced_observation_layouts():
+    """Reduced / float32 observation layouts gathered on the GPU are prefixes (resp. roundings) of Observation.as_array()."""
+    import os
+    from helpers import load_env
+    from pypownet_amd.engine import Engine
+    case, cfg, chronics = load_env('default118', conf={'solver': 'newton'})
+    eng = Engine(case, cfg, 8, chronics=chronics)
+    eng.reset()
+    eng.step(np.zeros((8, case.action_length), dtype=np.uint8))
+    full = eng.observations()
+    for lay in ('minimalist', 'ac_minimalist', 'full'):
+        o = eng.observations(layout=lay)
+        assert np.array_equal(o, full[:, :o.shape[1]], equal_nan=True)
+        o32 = eng.observations(layout=lay, dtype=np.float32)
+        assert np.array_equal(o32, o.astype(np.float32), equal_nan=True)
+    assert eng.observations(layout='minimalist').shape[1] < full.shape[1] // 2

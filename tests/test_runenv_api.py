@@ -135,3 +135,21 @@ def test_device_reward_equals_host_reward_signal(emu_lib):
         if done:
             env.process_game_over()
     assert 'IllegalActionException' in kinds and 'NoneType' in kinds, kinds
+
+
+def test_reduced_observation_layouts_are_prefixes(emu_lib):
+    """ppn_read_observation: MinimalistObservation / MinimalistACObservation arrays gathered on the device equal what the
+    reference's as_minimalist() / as_ac_minimalist() give on the Observation object; float32 = the rounded float64."""
+    env = make_env(emu_lib, 'default14_for_tests')
+    for _ in range(3):
+        obs, *_ = env.step(env.action_space.get_do_nothing_action())
+    o = env.observation_space.array_to_observation(obs)
+    eng = env.game.engine
+    mini = eng.observations(layout='minimalist')[0]
+    ac = eng.observations(layout='ac_minimalist')[0]
+    assert np.array_equal(mini, o.as_minimalist().as_array())
+    assert np.array_equal(ac, o.as_ac_minimalist().as_array())
+    assert np.array_equal(mini, obs[:len(mini)]) and np.array_equal(ac, obs[:len(ac)])
+    for lay, ref in (('minimalist', mini), ('ac_minimalist', ac), ('full', obs)):
+        f32 = eng.observations(layout=lay, dtype=np.float32)[0]
+        assert f32.dtype == np.float32 and np.array_equal(f32, ref.astype(np.float32))
