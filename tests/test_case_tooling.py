@@ -1,0 +1,28 @@
+"""Case tooling: the twin-busbar generator reproduces the shipped reference grids from their plain
+halves (what parameters/make_reference_grid.py does to a MATPOWER case)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tools'))
+from make_reference_grid import make_reference_grid  # noqa: E402
+from pypownet_amd.case import Case, load_case_file  # noqa: E402
+
+ENVS = os.path.join(os.path.dirname(__file__), 'golden', 'envs')
+
+
+@pytest.mark.parametrize('env', ['default14', 'default30', 'default118'])
+def test_twin_generator_reproduces_shipped_reference_grid(env):
+    ref = load_case_file(os.path.join(ENVS, env, 'level0', 'reference_grid.json'))
+    n = ref['bus'].shape[0] // 2
+    plain = dict(ref, bus=ref['bus'][:n][::-1].copy())          # the plain case, rows shuffled
+    plain['gen'] = ref['gen'][::-1].copy()
+    plain['gen'][:, 7] = 0                                      # out of service in the source: forced on
+    out = make_reference_grid(plain)
+    assert np.array_equal(out['bus'][:, :8], ref['bus'][:, :8]) and np.array_equal(out['bus'][:, 9:], ref['bus'][:, 9:])
+    assert np.all(out['bus'][:, 8] == 0)
+    assert np.array_equal(out['gen'][:, :7], ref['gen'][:, :7]) and np.all(out['gen'][:, 7] == 1)
+    assert np.array_equal(np.sort(out['branch'][:, :2], axis=0), np.sort(ref['branch'][:, :2], axis=0))
+    Case(out)      # accepted by the engine's case model (sorted ids, twins, one production / load per substation)
