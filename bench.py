@@ -8,7 +8,7 @@ process_game_over -- all device resident, inputs (chronic tensors, state, action
 
 Workload (BASELINE.json configs[2], SURVEY.md 8d "config 3"): default118, AC Newton (tol 1e-6, <=10 its),
 4096 environments per GPU, do-nothing agent, thermal limits synthesised so that the cascade is exercised:
-limit_k = max(50, round(Q0.98_t I_k(t))) A (tools/make_bench_limits.py), hard coefficient 2.0, soft break after 3
+limit_k = max(50, round(Q0.98_t I_k(t))) A (tests/tools/make_bench_limits.py), hard coefficient 2.0, soft break after 3
 consecutive overflowed steps (default118 YAML).
 Environment e plays chronic (e mod n_chronics) from row t0 = (37 e) mod T.
 
@@ -49,7 +49,7 @@ def load_workload():
 
 
 def bench_limits(case):
-    """Frozen synthetic limits of the workload (rule and generator: tools/make_bench_limits.py)."""
+    """Frozen synthetic limits of the workload (rule and generator: tests/tools/make_bench_limits.py)."""
     with open(os.path.join(ROOT, 'tests', 'golden', 'envs', ENV_NAME, 'bench_limits.json')) as f:
         lim = np.asarray(json.load(f)['limits_a'], dtype=np.float64)
     assert lim.shape == (case.nl,)

@@ -1,7 +1,7 @@
 """Debug aid: replay random actions; at step T lift the thermal limits so that the step is a single solve, then compare."""
 import os, sys
 import numpy as np
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from helpers import load_env
 import engine_checks as ec

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """Long-horizon lock-step of the GPU engine against the C oracle on the bench workload (do-nothing agent, cascade limits,
 auto reset): flags, line status, counters and chronic positions bit-exact, voltages <= 1e-8, over many chronic roll-overs
-and restarts.  Usage (GPU box): python tools/soak_parity.py [batch] [steps] [check_every]"""
+and restarts.  Usage (GPU box): python tests/tools/soak_parity.py [batch] [steps] [check_every]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from pypownet_amd.engine import Engine  # noqa: E402
