@@ -184,6 +184,7 @@ def main():
     kms, klaunch = eng.kernel_time(reset=True)
     ns1, ni1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
     done_now = int(eng.read('DONE').sum())
+    depth_now = float(eng.read('CASCADE_DEPTH').mean())
     stats = torch.tensor([elapsed, float(ns1 - ns0), float(ni1 - ni0), kms, float(klaunch)], dtype=torch.float64,
                          device=('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu')
     if world > 1:
@@ -221,7 +222,8 @@ def main():
                        'batch_per_gpu': B, 'solver': 'newton', 'parallelism': 'env-sharded x%d, no collective in the '
                                                                               'step loop' % world,
                        'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
-                       'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now},
+                       'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now,
+                       'mean_cascade_depth_last_step': depth_now},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
                          'kernel': 'ppn_kernel<W=2,K_STEP>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
