@@ -1,0 +1,31 @@
+"""Distribution of per-environment step-kernel times on the bench workload (-DPPN_PROF build, GPU box): shows that a launch
+lasts as long as its longest environment.  Usage: python tests/tools/chain_lengths.py"""
+import os, sys, numpy as np
+ROOT=os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/tools')
+import bench
+from pypownet_amd.engine import Engine
+lib=os.path.join(ROOT,'build','libppn_prof.so')
+case, conf, chronics = bench.load_workload()
+B=4096
+eng=Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS, _lib_path=lib)
+slots,t0=bench.env_assignment(0,B,chronics)
+eng.reset(chronic_slot=slots,t0=t0)
+act=np.zeros((B,case.action_length),dtype=np.uint8)
+for _ in range(6): eng.step(act, auto_reset=True)
+for rep in range(4):
+    zero=np.zeros((B,32),dtype=np.int64)
+    eng._check(eng._lib.ppn_write(eng._h,100,zero.ctypes.data,zero.nbytes),'w')
+    eng.kernel_time(reset=True)
+    s0,i0=eng.read('N_SOLVES').copy(),eng.read('N_ITERS').copy()
+    eng.step(act, auto_reset=True); eng.sync()
+    ds,di=eng.read('N_SOLVES')-s0,eng.read('N_ITERS')-i0
+    out=np.zeros((B,32),dtype=np.int64)
+    eng._check(eng._lib.ppn_read(eng._h,100,out.ctypes.data,out.nbytes,1,0),'r')
+    kt=eng.kernel_time()
+    w=out[:,15]*1e-8*1e6  # us
+    print('kernel %.0f us | env body wall us: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | sum/kernel = %.0f resident' % (kt[0]/kt[1]*1e3, w.mean(), np.percentile(w,50), np.percentile(w,90), np.percentile(w,99), w.max(), w.sum()/(kt[0]/kt[1]*1e3)))
+    top=np.argsort(-w)[:6]
+    for e in top:
+        print('   env %4d body %.0f us: %d solves %d iterations; prologue %.0f us, cascade %.0f us, restart %.0f us (flag %d)' % (e, w[e], ds[e], di[e], out[e,9]/2370., out[e,10]/2370., out[e,11]/2370., eng.read('FLAG')[e]))
+
