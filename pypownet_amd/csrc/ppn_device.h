@@ -86,6 +86,7 @@ __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #define LDS_OR(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
 #endif
 
+#define PPN_FILL_REGS 4   // fill-in entries of the Jacobian pattern kept per lane (4 x 64 = 256; beyond that the whole matrix is zeroed)
 #define PPN_NONE 0xFFu     // 'no internal index' in the u8 row -> bus table (max_active_buses <= 254)
 #define PPN_PI 3.14159265358979323846
 
@@ -123,7 +124,7 @@ struct DevCase {
   int nlev;
   int MCAP, TCAP;        // schedule capacities: pivot-neighbour pairs, update triples
   // per-environment schedule cache (global memory): byte offsets of its tables inside one environment's blob
-  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, cache_stride;
+  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, co_fill, cache_stride;
   const int *sub_le_ptr; // [nS+1]  CSR of line ends per substation
   const int *sub_le;     //         (line << 1) | end   (end 0 = origin, 1 = extremity)
   const int *elem_sub;   // [ntopo] substation of each element of [prods | loads | lines_or | lines_ex]

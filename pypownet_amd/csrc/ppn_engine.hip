@@ -611,6 +611,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     take(&d.co_le4, (size_t)nl * 8); take(&d.co_ly4, (size_t)nl * 8);
     take(&d.co_ymeta, (size_t)d.YCAP * 4); take(&d.co_lvl, (size_t)(nlev + 1) * 8);
     take(&d.co_tail, 32 + 512);         // dense tail: up to 16 bus indices (+pad), up to 16 x 16 entry map (u16)
+    take(&d.co_fill, (size_t)PPN_FILL_REGS * 64 * 2);   // fill-in entries of the pattern (the ones no Ybus entry covers)
     d.cache_stride = (int)o;
   }
   { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); }
