@@ -73,6 +73,8 @@ def test_emu_auto_reset_and_cascade_118(emu_lib):
 @pytest.mark.parametrize('env,solver,steps,batch', [('default14_for_tests_alpha', 'newton', 40, 6),
                                                      ('default14_for_tests_alpha', 'fdxb', 40, 6),
                                                      ('default14_for_tests_beta', 'fdxb', 30, 4),
+                                                     ('default30', 'newton', 30, 8),
+                                                     ('default30', 'fdxb', 20, 4),
                                                      ('default118', 'newton', 12, 3)])
 def test_emu_random_actions_vs_c_oracle(emu_lib, env, solver, steps, batch):
     import subprocess

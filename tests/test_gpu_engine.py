@@ -57,6 +57,8 @@ def test_gpu_auto_reset_and_cascade_118(solver):
 @pytest.mark.parametrize('env,solver,steps,batch', [('default14_for_tests_alpha', 'newton', 60, 64),
                                                      ('default14_for_tests_alpha', 'fdxb', 60, 64),
                                                      ('default14_for_tests_beta', 'fdxb', 40, 32),
+                                                     ('default30', 'newton', 50, 64),
+                                                     ('default30', 'fdxb', 30, 32),
                                                      ('default118', 'newton', 40, 96),
                                                      ('default118', 'fdxb', 25, 64)])
 def test_gpu_random_actions_vs_c_oracle(env, solver, steps, batch):
