@@ -303,6 +303,16 @@ static int filled_pairs(int nS, const std::vector<int>& f, const std::vector<int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Every entry point makes the engine's device current first: engines of different GPUs may live in one process (the
+// stream, the events and the allocations all belong to e->device).
+static inline void enter(const ppn_engine* e) {
+#ifndef PPN_EMU
+  if (e) (void)hipSetDevice(e->device);
+#else
+  (void)e;
+#endif
+}
+
 extern "C" const char* ppn_version(void) { return "pypownet_amd libppn 0.1 (gfx950)"; }
 
 extern "C" const char* ppn_last_error(const ppn_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -318,6 +328,7 @@ static void free_all(ppn_engine* e) {
 }
 
 extern "C" int ppn_destroy(ppn_engine* e) {
+  enter(e);
   if (!e) return PPN_E_INVALID;
   free_all(e);
   delete e;
@@ -675,11 +686,13 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
 }
 
 extern "C" int ppn_set_thermal_limits(ppn_engine* e, const double* limits) {
+  enter(e);
   if (!e || !limits) return PPN_E_INVALID;
   return dev_h2d((void*)e->dc.limits, limits, sizeof(double) * e->dc.nl, e->stream) ? fail(e, PPN_E_HIP, "limits upload failed") : PPN_OK;
 }
 
 extern "C" int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c) {
+  enter(e);
   if (!e || !c || c->T <= 0) return PPN_E_INVALID;
   if (slot < 0 || slot > (int)e->chronics.size()) return fail(e, PPN_E_INVALID, "chronic slots must be loaded in order");
   const DevCase& d = e->dc;
@@ -758,6 +771,7 @@ static KArgs make_args(ppn_engine* e, bool sim_state) {
 }
 
 extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* chronic_slot, const int32_t* t0) {
+  enter(e);
   if (!e) return PPN_E_INVALID;
   int rc = sync_chronics(e);
   if (rc) return rc;
@@ -812,6 +826,7 @@ extern "C" int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p) {
 
 extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
                         int32_t auto_reset) {
+  enter(e);
   if (!e || !actions) return PPN_E_INVALID;
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
   const u8* dact = actions;
@@ -867,6 +882,7 @@ static int gather_rows(ppn_engine* e, void* dst, const void* src, const int* d_i
 
 extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device,
                                        const int32_t* env_ids, int32_t n) {
+  enter(e);
   if (!e || !actions || !env_ids || n <= 0) return PPN_E_INVALID;
   for (int c = 0; c < n; ++c) if (env_ids[c] < 0 || env_ids[c] >= e->batch) return fail(e, PPN_E_INVALID, "ppn_simulate_candidates: environment %d out of range", env_ids[c]);
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
@@ -910,6 +926,7 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
 }
 
 extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
+  enter(e);
   if (!e) return PPN_E_INVALID;
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
   KArgs a = make_args(e, false);
@@ -922,6 +939,7 @@ extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
 }
 
 extern "C" int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_t* valid) {
+  enter(e);
   if (!e || !actions || !valid) return PPN_E_INVALID;
   if (dev_h2d(e->d_actions, actions, (size_t)e->batch * e->dc.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
   KArgs a = make_args(e, false);
@@ -932,6 +950,7 @@ extern "C" int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_
 }
 
 extern "C" int ppn_runpf_batch(ppn_engine* e) {
+  enter(e);
   if (!e) return PPN_E_INVALID;
   KArgs a = make_args(e, false);
   if (launch<K_RUNPF>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "runpf kernel launch failed: %s", dev_err());
@@ -939,6 +958,7 @@ extern "C" int ppn_runpf_batch(ppn_engine* e) {
 }
 
 extern "C" int ppn_sync(ppn_engine* e) {
+  enter(e);
   if (!e) return PPN_E_INVALID;
 #ifndef PPN_EMU
   if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
@@ -955,6 +975,7 @@ extern "C" void* ppn_stream(ppn_engine* e) {
 }
 
 extern "C" int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, int64_t* launches) {
+  enter(e);
   if (!e) return PPN_E_INVALID;
 #ifndef PPN_EMU
   if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
@@ -978,6 +999,7 @@ static int obs_length(const DevCase& d, int layout) {     // environment.py:406-
 
 extern "C" int ppn_read_observation(ppn_engine* e, int32_t layout, int32_t as_f32, void* dst, size_t bytes, int32_t to_host,
                                     int32_t from_simulation) {
+  enter(e);
   if (!e || !dst || layout < 0 || layout > 2) return PPN_E_INVALID;
   if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read_observation: no candidates have been simulated");
   const size_t B = (from_simulation == 2) ? (size_t)e->n_cand : (size_t)e->batch;
@@ -1000,6 +1022,7 @@ extern "C" int32_t ppn_observation_length(const ppn_engine* e, int32_t layout) {
 }
 
 extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation) {
+  enter(e);
   if (!e || !dst) return PPN_E_INVALID;
   if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read: no candidates have been simulated");
   const DevState& s = (from_simulation == 2) ? e->cand : (from_simulation ? e->sim : e->st);
@@ -1015,6 +1038,7 @@ extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int
 }
 
 extern "C" int ppn_write(ppn_engine* e, ppn_field f, const void* src, size_t bytes) {
+  enter(e);
   if (!e || !src) return PPN_E_INVALID;
   FieldInfo fi; bool w;
   if (!field_info(e, f, &fi, &w) || !w) return fail(e, PPN_E_INVALID, "ppn_write: field %d is not writable", (int)f);
