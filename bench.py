@@ -147,8 +147,15 @@ def main():
     if backend != 'nccl':
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend, rank=rank, world_size=world)   # nccl = RCCL over xGMI
+    use_dist = world > 1 or os.environ.get('PPN_BENCH_FORCE_DIST') == '1'   # (the latter: 1-rank smoke test of the RCCL path)
+    if use_dist:
+        if backend == 'nccl':
+            try:      # bind the communicator to this rank's GPU up front (no lazy device guess in barrier())
+                dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            except TypeError:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)   # nccl = RCCL over xGMI
 
     from pypownet_amd.engine import Engine
     case, conf, chronics = load_workload()
@@ -168,7 +175,7 @@ def main():
     ns0, ni0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
     eng.kernel_time(reset=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     eng.sync()
@@ -177,7 +184,7 @@ def main():
         eng.step_device(aptr, auto_reset=True)
     eng.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
 
@@ -187,7 +194,7 @@ def main():
     depth_now = float(eng.read('CASCADE_DEPTH').mean())
     stats = torch.tensor([elapsed, float(ns1 - ns0), float(ni1 - ni0), kms, float(klaunch)], dtype=torch.float64,
                          device=('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu')
-    if world > 1:
+    if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -237,7 +244,7 @@ def main():
                 out['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port',
                                        'sample': 'failed: %s' % ex}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
