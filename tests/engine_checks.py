@@ -216,7 +216,7 @@ def random_actions(case, rng, batch, p_node=0.6, p_line=0.3):
     return acts
 
 
-def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='newton', seed=1234, conf=None):
+def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='newton', seed=1234, conf=None, **engine_kw):
     """Lock-step with the C oracle under random node-splitting / line-switching actions (dynamic Ybus rebuild every
     step, illegal-action repair, cooldowns, islanding, game overs + auto reset): flags, topology, counters bit-exact,
     voltages <= 1e-8 on live environments."""
@@ -229,7 +229,7 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
     case, cfg, chronics = load_env(envname, conf=cf)
     case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
     prefix = 'orc_' if (lib_path and 'liboracle' in lib_path) else 'ppn_'
-    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, _lib_prefix=prefix)
+    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, _lib_prefix=prefix, **engine_kw)
     orc = Engine(case, cfg, batch, chronics=chronics, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
                  _lib_prefix='orc_')
     rng = np.random.default_rng(seed)

@@ -92,3 +92,8 @@ def test_emu_device_reward_matches_restatement(emu_lib, env, steps, batch):
 @pytest.mark.parametrize('env,batch,k', [('default14_for_tests_alpha', 12, 5), ('default118', 6, 3)])
 def test_emu_candidate_search_equals_simulate(emu_lib, env, batch, k):
     ec.check_candidate_search(emu_lib, env, batch, k)
+
+
+def test_emu_intermediate_busbar_capacity(emu_lib):
+    st = ec.check_random_actions_vs_c_oracle(emu_lib, 'default118', 8, 4, 'newton', seed=77, max_active_buses=150)
+    assert st['split_buses'] > 0

@@ -121,3 +121,11 @@ def test_gpu_reduced_observation_layouts():
         o32 = eng.observations(layout=lay, dtype=np.float32)
         assert np.array_equal(o32, o.astype(np.float32), equal_nan=True)
     assert eng.observations(layout='minimalist').shape[1] < full.shape[1] // 2
+
+
+@pytest.mark.parametrize('cap,solver', [(150, 'newton'), (128, 'newton'), (150, 'fdxb')])
+def test_gpu_intermediate_busbar_capacities(cap, solver):
+    """max_active_buses between the substation count and every busbar: the W = 3 (150) and W = 2 (128) kernels with spare
+    busbars, against the oracle under random node splitting; no environment may hit the capacity flag."""
+    st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 20, 48, solver, seed=77, max_active_buses=cap)
+    assert st['split_buses'] > 0
