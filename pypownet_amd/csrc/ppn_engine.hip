@@ -69,6 +69,7 @@ struct ppn_engine {
   std::vector<void*> allocs;
   std::vector<HostChronic> chronics;
   bool chronics_dirty = true;
+  bool newton = false;        // rules: AC mode with the Newton-Raphson solver -> the NT = 1 kernels
   bool maybe_dead = true;     // some environment may be over at the next ppn_step (see ppn_step)
   std::vector<void*> chronic_allocs;
   hipStream_t stream = 0;
@@ -138,7 +139,7 @@ struct KArgs {
 };
 
 #ifndef PPN_EMU
-template <int W, int KIND>
+template <int W, int KIND, int NT>
 #ifndef PPN_WAVES_PER_EU
 #define PPN_WAVES_PER_EU 1
 #endif
@@ -148,10 +149,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPN_WAV
   ppn_carve(a.d, W, smem, &S);
   const int env = (KIND == K_STEP && a.perm) ? a.perm[blockIdx.x] : (int)blockIdx.x;
   const int lane0 = threadIdx.x;
-  if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, lane0);
-  else if (KIND == K_GAMEOVER) body_game_over<W>(a.d, a.st, S, a.valid, env, lane0);
-  else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, lane0);
-  else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, lane0);
+  if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, lane0);
+  else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, env, lane0);
+  else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, lane0);
+  else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, lane0);
   else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, lane0);
   else if (KIND == K_OBS) { if (a.obs_f32) body_obs<float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, lane0); else body_obs<double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, lane0); }
 }
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(1024) ppn_order_kernel(const float* prio, int*
 }
 #endif
 
-template <int W, int KIND>
+template <int W, int KIND, int NT>
 static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
 #ifdef PPN_EMU
   (void)timed;
@@ -194,10 +195,10 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   ppn_carve(a.d, W, base, &S);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, 0xA5, e->lds_bytes);   // LDS is NOT zero-initialised on the GPU either
-    if (KIND == K_STEP) body_step<W>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, 0);
-    else if (KIND == K_GAMEOVER) body_game_over<W>(a.d, a.st, S, a.valid, env, 0);
-    else if (KIND == K_RESET) body_reset<W>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
-    else if (KIND == K_RUNPF) body_runpf<W>(a.d, a.st, S, env, 0);
+    if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, 0);
+    else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, env, 0);
+    else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
+    else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
     else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, 0);
     else if (KIND == K_OBS) { if (a.obs_f32) body_obs<float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0); }
   }
@@ -212,19 +213,26 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     (void)hipEventRecord(e0, e->stream);
   }
-  hipLaunchKernelGGL((ppn_kernel<W, KIND>), dim3(nblocks), dim3(64), e->lds_bytes, e->stream, a);
+  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), e->lds_bytes, e->stream, a);
   if (timed) { (void)hipEventRecord(e1, e->stream); e->launches++; }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
 }
 
+// Kernels that contain a solve exist in two flavours (NT = 1: AC Newton-Raphson only; NT = 0: fast-decoupled XB / DC);
+// the others only as NT = 0.
+template <int W, int KIND>
+static int launch_nt(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
+  constexpr bool solves = (KIND == K_STEP || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
+  if (solves && e->newton) return launch_w<W, KIND, solves ? 1 : 0>(e, a, nblocks, timed);
+  return launch_w<W, KIND, 0>(e, a, nblocks, timed);
+}
 template <int KIND>
 static int launch(ppn_engine* e, const KArgs& a, int nblocks, bool timed = false) {
   switch (e->W) {
-    case 1: return launch_w<1, KIND>(e, a, nblocks, timed);
-    case 2: return launch_w<2, KIND>(e, a, nblocks, timed);
-    case 3: return launch_w<3, KIND>(e, a, nblocks, timed);
-    default: return launch_w<4, KIND>(e, a, nblocks, timed);
+    case 1: return launch_nt<1, KIND>(e, a, nblocks, timed);
+    case 2: return launch_nt<2, KIND>(e, a, nblocks, timed);
+    default: return launch_nt<4, KIND>(e, a, nblocks, timed);
   }
 }
 
@@ -232,12 +240,10 @@ static int launch(ppn_engine* e, const KArgs& a, int nblocks, bool timed = false
 template <int W>
 static int set_lds_attr(size_t bytes) {
   int rc = 0;
-  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_GAMEOVER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_RESET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_RUNPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_VALID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
-  rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K_OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+#define PPN_ATTR(K, N) rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
+  PPN_ATTR(K_STEP, 0) PPN_ATTR(K_STEP, 1) PPN_ATTR(K_GAMEOVER, 0) PPN_ATTR(K_GAMEOVER, 1) PPN_ATTR(K_RESET, 0) PPN_ATTR(K_RESET, 1)
+  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0)
+#undef PPN_ATTR
   return rc;
 }
 #endif
@@ -590,7 +596,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (NB > 254) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "more than 254 active busbars are not supported"); }
   if (NB < nS) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "max_active_buses (%d) is below the number of substations (%d)", NB, nS); }
   d.NB = NB;
-  e->W = (NB + 63) / 64;
+  e->W = (NB <= 64) ? 1 : (NB <= 128 ? 2 : 4);      // bitset words of the kernel variant (no 3-word build)
   d.YCAP = NB + 2 * nl;
   {
     const int ypl = (e->W == 1) ? 4 : (e->W == 2 ? 8 : (e->W == 3 ? 10 : 12));   // Ybus entries held per lane (registers)
@@ -653,6 +659,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
 
   DevRules& R = d.R;
   R.mode = r->mode; R.solver = r->solver; R.max_it = r->max_it; R.tol = r->tol;
+  e->newton = (r->mode != PPN_MODE_DC && r->solver == 1);
   R.hard_coef = r->hard_overflow_coefficient; R.n_soft_consecutive = r->n_timesteps_consecutive_soft_overflow_breaks;
   R.n_hard_broken = r->n_timesteps_hard_overflow_is_broken; R.n_soft_broken = r->n_timesteps_soft_overflow_is_broken;
   R.horizon = r->n_timesteps_horizon_maintenance;
@@ -677,7 +684,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
 #ifndef PPN_EMU
   int rc_attr = 0;
   switch (e->W) { case 1: rc_attr = set_lds_attr<1>(e->lds_bytes); break; case 2: rc_attr = set_lds_attr<2>(e->lds_bytes); break;
-                  case 3: rc_attr = set_lds_attr<3>(e->lds_bytes); break; default: rc_attr = set_lds_attr<4>(e->lds_bytes); }
+                  default: rc_attr = set_lds_attr<4>(e->lds_bytes); }
   if (rc_attr) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, dev_err()); }
   if (hipStreamSynchronize(e->stream) != hipSuccess) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "upload failed: %s", dev_err()); }
 #endif
