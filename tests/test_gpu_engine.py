@@ -125,7 +125,7 @@ def test_gpu_reduced_observation_layouts():
 
 @pytest.mark.parametrize('cap,solver', [(150, 'newton'), (128, 'newton'), (150, 'fdxb')])
 def test_gpu_intermediate_busbar_capacities(cap, solver):
-    """max_active_buses between the substation count and every busbar: the W = 3 (150) and W = 2 (128) kernels with spare
-    busbars, against the oracle under random node splitting; no environment may hit the capacity flag."""
+    """max_active_buses between the substation count and every busbar: the 4-word kernels below full capacity (150) and the
+    2-word kernels with spare busbars (128), against the oracle under random node splitting; no environment may hit the capacity flag."""
     st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 20, 48, solver, seed=77, max_active_buses=cap)
     assert st['split_buses'] > 0
