@@ -243,7 +243,9 @@ int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, int64_t* lau
 /* ---- introspection --------------------------------------------------------------------------------- */
 int32_t ppn_dim(const ppn_engine* e, int32_t which);   /* 0 nS, 1 nP, 2 nL, 3 nl, 4 action_len, 5 obs_len,
                                                           6 batch, 7 lds_bytes, 8 max_active_buses,
-                                                          9 lu_capacity, 10 n_chronic_slots, 11 base LU fill */
+                                                          9 lu_capacity, 10 n_chronic_slots, 11 base LU fill,
+                                                          12-14 capacities of the elimination schedule (filled 2x2
+                                                          block entries, Schur pair records, triple records) */
 const char* ppn_version(void);
 
 #ifdef __cplusplus

@@ -373,6 +373,9 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
   if ((int)f == 100) {   /* phase cycle counters of -DPPN_PROF builds (tools/profile_phases.py) */
     fi->elem = sizeof(long long); fi->n = 32; fi->off = offsetof(DevState, prof); *writable = true; return true;
   }
+  if ((int)f == 101) {   /* raw schedule cache blobs (tools/fill_survey.py reads the headers: fill, records) */
+    fi->elem = 1; fi->n = d.cache_stride; fi->off = offsetof(DevState, ws_cache); *writable = false; return true;
+  }
 #define FI(member, type, count, w) { fi->elem = sizeof(type); fi->n = (count); fi->off = offsetof(DevState, member); *writable = (w); return true; }
   switch (f) {
     case PPN_F_VM: FI(vm, double, d.nrows, true)
@@ -431,6 +434,7 @@ extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
     case 0: return d.nS; case 1: return d.nP; case 2: return d.nL; case 3: return d.nl;
     case 4: return d.alen; case 5: return d.obslen; case 6: return e->batch; case 7: return (int32_t)e->lds_bytes;
     case 8: return d.NB; case 9: return d.LUCAP; case 10: return (int32_t)e->chronics.size(); case 11: return e->base_fill;
+    case 12: return d.ECAP; case 13: return d.MCAP; case 14: return d.TCAP;
     default: return -1;
   }
 }
@@ -614,8 +618,11 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   int ecap = r->lu_capacity > 0 ? (r->lu_capacity + 3) / 4 : 0;
   if (ecap <= 0) {
     const double extra = (NB > nS) ? (double)(NB - nS) / nS : 0.0;   // share of busbars that may be split off
-    // line cuts never add fill: without spare busbars the base fill is exact
-    ecap = (NB > nS) ? (int)(pairs * (1.10 + 2.0 * extra)) + 16 : pairs;
+    // line cuts never add fill: without spare busbars the base fill is exact.  Splitting a substation spreads its lines
+    // over two busbars, so the graph gets sparser as it grows: over 30 k random topologies of IEEE-118 with up to 210
+    // active busbars the largest filled pattern was 1.34x the base one (tools/fill_survey.py); the default leaves
+    // 1.15x + 1.0x per doubling (2.15x with every busbar active), rules.lu_capacity overrides it
+    ecap = (NB > nS) ? (int)(pairs * (1.15 + 1.0 * extra)) + 16 : pairs;
   }
   d.ECAP = (ecap + 7) & ~7;
   d.LUCAP = 4 * d.ECAP;

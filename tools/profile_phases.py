@@ -28,19 +28,29 @@ def main():
                            '-DPPN_PROF', os.path.join(ROOT, 'pypownet_amd', 'csrc', 'ppn_engine.hip'), '-o', lib])
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    split = len(sys.argv) > 3 and sys.argv[3] == 'split'     # random node-splitting actions, every busbar may be active
     case, conf, chronics = bench.load_workload()
-    eng = Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS,
-                 _lib_path=lib)
+    eng = Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case),
+                 max_active_buses=(int(sys.argv[4]) if len(sys.argv) > 4 else 2 * case.nS) if split else case.nS, _lib_path=lib)
     slots, t0 = bench.env_assignment(0, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
     act = np.zeros((B, case.action_length), dtype=np.uint8)
-    eng.step(act, auto_reset=True)
+    if split:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from bench_configs import random_node_splitting
+        rng = np.random.default_rng(1234)
+        for _ in range(8):
+            eng.step(random_node_splitting(case, rng, B), auto_reset=True)
+        acts = [random_node_splitting(case, rng, B) for _ in range(8)]
+    else:
+        acts = [act]
+    eng.step(acts[0], auto_reset=True)
     zero = np.zeros((B, 32), dtype=np.int64)
     eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
     eng.kernel_time(reset=True)
     s0, i0 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
-    for _ in range(steps):
-        eng.step(act, auto_reset=True)
+    for k in range(steps):
+        eng.step(acts[(k + 1) % len(acts)], auto_reset=True)
     eng.sync()
     s1, i1 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
     out = np.zeros((B, 32), dtype=np.int64)
