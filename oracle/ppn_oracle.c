@@ -71,7 +71,8 @@ typedef struct {
   int *rec, *lcd, *ncd, *soft;
   int done, dead, succ, flag, ill, depth, nsolve, niter, slot, row, nlc, npc, epoch;
   int illn[3], actsw[2];   /* IllegalActionException contents as counts; node / line switches of the action after the step */
-  double min_vm;    /* test diagnostic: smallest |V| of an active bus over the successful solves of the last step */
+  double min_vm;    /* test diagnostic: smallest |V| of an active bus over the solves of the last step (the last
+                       iterate of a failed one included: a solve that reaches V = 0 exactly fails on the NaN it produces) */
 } OEnv;
 
 struct orc_engine {
@@ -400,6 +401,7 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
         if (ivm[i] >= 0) vm[i] -= dx[ivm[i]];
         const cplx v = vm[i] * cexp(I * va[i]);
         vm[i] = cabs(v); va[i] = carg(v);
+        if (vm[i] < e->min_vm) e->min_vm = vm[i];   /* test diagnostic (an iterate at V = 0 exactly turns the next one into NaN) */
       }
     }
     free(ith); free(ivm); free(pm); free(V); free(Ib); free(F); free(dx);
@@ -504,7 +506,7 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
     }
     free(V);
     rc = (success && !bad) ? 0 : 1;
-    if (success) for (int i = 0; i < n; ++i) if (vm[i] < e->min_vm) e->min_vm = vm[i];
+    for (int i = 0; i < n; ++i) if (vm[i] < e->min_vm) e->min_vm = vm[i];   /* NaN compares false */
   }
 done:
   free(touched); free(hasgen); free(genon); free(e2i); free(i2e); free(typ); free(perm);
