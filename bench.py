@@ -237,6 +237,17 @@ def main():
                          'algorithmic_bytes_per_env_step': b_step},
             'cpu_baseline': None,
         }
+        if world == 1:
+            # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
+            # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`
+            host_actions = np.zeros((B, case.action_length), dtype=np.uint8)
+            n_host = max(3, min(20, args.steps))
+            eng.sync()
+            t_h = time.perf_counter()
+            for _ in range(n_host):
+                eng.step(host_actions, auto_reset=True)
+                eng.read('DONE'); eng.read('FLAG'); eng.read('REWARD')
+            out['config']['host_boundary_env_steps_per_s'] = B * n_host / (time.perf_counter() - t_h)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(case, conf, chronics, limits)
