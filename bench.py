@@ -130,6 +130,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--single-controller', action='store_true',
+                    help="BASELINE.json configs[3]'s exchange variant: every step rank 0 scatters the actions of ALL "
+                         'environments and gathers (done, flag, reward) over RCCL; default: policy per GPU, no collective')
     args = ap.parse_args()
 
     import torch
@@ -175,13 +178,37 @@ def main():
     ns0, ni0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
     eng.kernel_time(reset=True)
 
+    exchange = None
+    if args.single_controller and use_dist:
+        dev = 'cuda:%d' % local_rank
+        all_actions = [torch.zeros_like(actions) for _ in range(world)] if rank == 0 else None   # the controller's choice
+        d_done = torch.empty((B,), dtype=torch.uint8, device=dev)
+        d_flag = torch.empty((B,), dtype=torch.int32, device=dev)
+        d_rew = torch.empty((B, 5), dtype=torch.float64, device=dev)
+        gathered = [torch.empty((B, 3), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+
+        def exchange():
+            dist.scatter(actions, all_actions, src=0)                # [B x action_length] u8 to every rank
+            torch.cuda.synchronize()
+            eng.step_device(aptr, auto_reset=True)
+            eng.read_into_device('DONE', d_done.data_ptr(), d_done.numel())
+            eng.read_into_device('FLAG', d_flag.data_ptr(), 4 * d_flag.numel())
+            eng.read_into_device('REWARD', d_rew.data_ptr(), 8 * d_rew.numel())
+            eng.sync()
+            res = torch.stack([d_done.double(), d_flag.double(), d_rew.sum(dim=1)], dim=1)
+            dist.gather(res, gathered, dst=0)                        # 24 B per environment back to the controller
+        exchange()
+
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     eng.sync()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        eng.step_device(aptr, auto_reset=True)
+        if exchange is not None:
+            exchange()
+        else:
+            eng.step_device(aptr, auto_reset=True)
     eng.sync()
     torch.cuda.synchronize()
     if use_dist:
@@ -226,8 +253,10 @@ def main():
             'data': 'synthetic: IEEE-118 case + reference chronic series (fixture), synthetic thermal limits',
             'config': {'workload': 'default118 AC Newton-Raphson (tol 1e-6), batch=%d envs/GPU with cascading-failure '
                                    'inner loop, do-nothing agent, auto game-over reset' % B,
-                       'batch_per_gpu': B, 'solver': 'newton', 'parallelism': 'env-sharded x%d, no collective in the '
-                                                                              'step loop' % world,
+                       'batch_per_gpu': B, 'solver': 'newton',
+                       'parallelism': ('env-sharded x%d, single controller: RCCL scatter of actions + gather of done/flag/'
+                                       'reward every step' if exchange is not None else
+                                       'env-sharded x%d, no collective in the step loop') % world,
                        'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
                        'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now,
                        'mean_cascade_depth_last_step': depth_now},

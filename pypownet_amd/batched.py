@@ -116,6 +116,47 @@ class BatchedRunEnv(object):
             return None
         return np.concatenate([o.cpu().numpy()[:b - a_] for o, (a_, b) in zip(out, sizes)])
 
+    def scatter_from_root(self, array, root=0):
+        """The other half of the single-controller mode: `root` holds a [global_batch x ...] array (the
+        actions its policy chose for every environment), each rank receives the rows of its shard."""
+        import torch
+        import torch.distributed as dist
+        if self.world_size == 1:
+            return np.asarray(array)
+        sizes = [shard_range(self.global_batch, r, self.world_size) for r in range(self.world_size)]
+        mx = max(b - a_ for a_, b in sizes)
+        meta = [None]
+        if self.rank == root:
+            a = np.ascontiguousarray(array)
+            assert a.shape[0] == self.global_batch
+            meta = [(a.shape[1:], a.dtype.str)]
+        dist.broadcast_object_list(meta, src=root)
+        tail, dt = meta[0]
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        recv = torch.empty((mx,) + tuple(tail), dtype=torch.from_numpy(np.empty(0, dtype=np.dtype(dt))).dtype, device=dev)
+        parts = None
+        if self.rank == root:
+            parts = []
+            for a_, b in sizes:
+                pad = np.zeros((mx,) + tuple(tail), dtype=np.dtype(dt))
+                pad[:b - a_] = a[a_:b]
+                parts.append(torch.from_numpy(pad).to(dev))
+        dist.scatter(recv, parts, src=root)
+        return recv.cpu().numpy()[:self.batch]
+
+    def controller_step(self, global_actions=None, root=0, auto_reset=True):
+        """One step of the single-controller mode: scatter the root's [global_batch x action_length] actions, step the
+        shard, gather (done, flag, reward) of every environment on the root.  Returns (done, flag, reward) on the root,
+        None elsewhere.  Observations stay on their GPU (gather_to_root(env.engine.observations()) fetches them)."""
+        acts = self.scatter_from_root(global_actions, root=root)
+        self.engine.step(acts, auto_reset=auto_reset)
+        e = self.engine
+        res = np.stack([e.read('DONE').astype(np.float64), e.read('FLAG').astype(np.float64), e.read('REWARD').sum(axis=1)], axis=1)
+        full = self.gather_to_root(res, root=root)
+        if full is None:
+            return None
+        return full[:, 0].astype(bool), full[:, 1].astype(np.int32), full[:, 2]
+
     def all_reduce_stats(self, values):
         import torch
         import torch.distributed as dist

@@ -23,9 +23,16 @@ env.reset()
 for t in range(5):
     obs, done, flag, ill = env.step(np.zeros((env.batch, env.action_length), dtype=np.uint8))
 full = env.gather_to_root(obs)
+# single-controller mode: the root's actions are scattered, (done, flag, reward) gathered (one substation switched in env 5)
+ga = None
+if rank == 0:
+    ga = np.zeros((7, env.action_length), dtype=np.uint8)
+    ga[5, 0] = 1
+ctl = env.controller_step(ga)
 tot = env.all_reduce_stats([env.engine.read('N_SOLVES').sum(), env.batch])
 if rank == 0:
     np.save(%(out)r, full)
+    np.save(%(out)r + '.ctl.npy', np.stack([ctl[0].astype(np.float64), ctl[1].astype(np.float64), ctl[2]]))
     assert tot[1] == 7
 dist.destroy_process_group()
 '''
@@ -52,3 +59,10 @@ def test_two_rank_shards_equal_single_process(emu_lib, tmp_path):  # noqa: F811
         obs, done, flag, ill = single.step(np.zeros((7, single.action_length), dtype=np.uint8))
     assert gathered.shape == obs.shape == (7, single.observation_length)
     assert np.array_equal(gathered, obs)
+    ga = np.zeros((7, single.action_length), dtype=np.uint8)
+    ga[5, 0] = 1
+    done, flag, reward = single.controller_step(ga)
+    ctl = np.load(out + '.ctl.npy')
+    assert np.array_equal(ctl[0].astype(bool), done) and np.array_equal(ctl[1].astype(np.int32), flag)
+    assert np.array_equal(ctl[2], reward)
+    assert np.array_equal(single.engine.read('PRODS_NODES')[5, :1], [1]) or single.engine.read('ILLEGAL')[5] != 0
