@@ -125,6 +125,10 @@ struct DevCase {
   int MCAP, TCAP;        // schedule capacities: pivot-neighbour pairs, update triples
   // per-environment schedule cache (global memory): byte offsets of its tables inside one environment's blob
   int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, co_fill, cache_stride;
+  // the schedule of the reference topology (every element on busbar 0), shared by all environments: one copy of the
+  // tables and records that stays in the L2s instead of `batch` private ones streaming from HBM.  Null until the first
+  // ppn_reset has produced it.
+  const u8 *b_cache; const u64 *b_tri, *b_pair; const unsigned *b_piv;
   const int *sub_le_ptr; // [nS+1]  CSR of line ends per substation
   const int *sub_le;     //         (line << 1) | end   (end 0 = origin, 1 = extremity)
   const int *elem_sub;   // [ntopo] substation of each element of [prods | loads | lines_or | lines_ex]

@@ -71,6 +71,10 @@ struct ppn_engine {
   bool chronics_dirty = true;
   bool newton = false;        // rules: AC mode with the Newton-Raphson solver -> the NT = 1 kernels
   bool maybe_dead = true;     // some environment may be over at the next ppn_step (see ppn_step)
+  // shared schedule of the reference topology (DevCase::b_*): allocated by ppn_create, filled from the first environment
+  // of the first ppn_reset (whose solve built it), then handed to every later launch
+  u8* base_cache = nullptr; u64 *base_tri = nullptr, *base_pair = nullptr; unsigned* base_piv = nullptr;
+  bool base_ready = false;
   std::vector<void*> chronic_allocs;
   hipStream_t stream = 0;
   size_t lds_bytes = 0;
@@ -681,6 +685,9 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (!(R.tol > 0)) R.tol = 1e-6;
 
   if (alloc_state(e, &e->st, (size_t)batch) || alloc_state(e, &e->sim, (size_t)batch)) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
+  e->base_cache = dalloc<u8>(e, (size_t)d.cache_stride); e->base_tri = dalloc<u64>(e, (size_t)d.TCAP);
+  e->base_pair = dalloc<u64>(e, (size_t)d.MCAP); e->base_piv = dalloc<unsigned>(e, (size_t)d.NB);
+  if (!e->base_cache || !e->base_tri || !e->base_pair || !e->base_piv) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
   e->d_actions = dalloc<u8>(e, (size_t)batch * d.alen);
   e->d_valid = dalloc<u8>(e, batch);
   e->d_perm = dalloc<int>(e, batch);
@@ -807,6 +814,26 @@ extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const
   a.ids = e->d_ids; a.slots = e->d_ids + e->batch; a.t0 = e->d_ids + 2 * e->batch;
   if (launch<K_RESET>(e, a, n)) return fail(e, PPN_E_HIP, "reset kernel launch failed: %s", dev_err());
   e->maybe_dead = true;
+  if (!e->base_ready) {
+    // The environments just reset stand in the reference topology and have built its schedule: the first one's copy
+    // becomes the shared one (stream-ordered copies; the one synchronisation checks that the build succeeded).
+    const char* off = getenv("PPN_SHARED_SCHEDULE");
+    if (!(off && off[0] == '0')) {
+      const DevCase& d = e->dc;
+      const size_t env = (size_t)(env_ids ? env_ids[0] : 0);
+      int rcc = dev_d2d(e->base_cache, e->st.ws_cache + env * (size_t)d.cache_stride, (size_t)d.cache_stride, e->stream);
+      rcc |= dev_d2d(e->base_tri, e->st.ws_tri + env * (size_t)d.TCAP, sizeof(u64) * (size_t)d.TCAP, e->stream);
+      rcc |= dev_d2d(e->base_pair, e->st.ws_pair + env * (size_t)d.MCAP, sizeof(u64) * (size_t)d.MCAP, e->stream);
+      rcc |= dev_d2d(e->base_piv, e->st.ws_piv + env * (size_t)d.NB, sizeof(unsigned) * (size_t)d.NB, e->stream);
+      int hdr[16] = {0};
+      rcc |= dev_d2h(hdr, e->base_cache, sizeof hdr, e->stream);
+      if (rcc) return fail(e, PPN_E_HIP, "ppn_reset: shared schedule copy failed: %s", dev_err());
+      if (hdr[0] == 1) {
+        e->dc.b_cache = e->base_cache; e->dc.b_tri = e->base_tri; e->dc.b_pair = e->base_pair; e->dc.b_piv = e->base_piv;
+        e->base_ready = true;
+      }
+    }
+  }
   return PPN_OK;
 }
 
