@@ -19,3 +19,4 @@ PPN_LAUNCH_ORDER=0 python bench.py --no-cpu-baseline > $OUT/bench_no_launch_orde
 python bench.py --batch 32768 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_b32768.json 2>/dev/null
 tail -1 $OUT/bench.json | cut -c1-400
 ls $OUT $OUT/stats | head -30
+# afterwards, in the development container: python tools/summarize_pmc.py $TAG  (-> profiles/)
