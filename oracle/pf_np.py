@@ -273,6 +273,24 @@ def _make_bdc(baseMVA, bus, branch):
     return Bbus.tocsr(), Bf, Pbusinj, Pfinj
 
 
+def _connected(n, f, t, start):
+    """Every kept bus reachable from `start` over the in-service branches."""
+    adj = [[] for _ in range(n)]
+    for a, b in zip(f, t):
+        adj[a].append(b)
+        adj[b].append(a)
+    seen = np.zeros(n, dtype=bool)
+    seen[start] = True
+    stack = [start]
+    while stack:
+        u = stack.pop()
+        for v in adj[u]:
+            if not seen[v]:
+                seen[v] = True
+                stack.append(v)
+    return bool(seen.all())
+
+
 def runpf(baseMVA, bus, gen, branch, dc=False, alg=ALG_FDXB, tol=1e-6, max_it=None, info=None):
     """``(bus, gen, branch), success = runpf(...)`` on EXTERNAL MATPOWER-format arrays (copies are returned).
 
@@ -320,6 +338,12 @@ def runpf(baseMVA, bus, gen, branch, dc=False, alg=ALG_FDXB, tol=1e-6, max_it=No
     gbus = igen[on, GEN_BUS].astype(int)
 
     if dc:
+        # Islanded grid: B[pvpq, pvpq] is singular and what PYPOWER's spsolve returns then is SuperLU's rounding luck --
+        # NaN (the reference's _contains_nan turns it into an outage, grid.py:103-110, 263-264), a RuntimeError on some
+        # paths ("not connexe", grid.py:230), or finite garbage with which the game would go on.  The build defines the
+        # outcome (SURVEY.md finding 5: exact connectivity test): an island without the reference bus is "not connexe".
+        if not _connected(len(ibus), ibr[:, F_BUS].astype(int), ibr[:, T_BUS].astype(int), int(ref[0])):
+            raise RuntimeError('grid is not connected')
         Va0 = ibus[:, VA] * (np.pi / 180)
         B, Bf, Pbusinj, Pfinj = _make_bdc(baseMVA, ibus, ibr)
         Pbus = _make_sbus(baseMVA, ibus, igen).real - Pbusinj - ibus[:, GS] / baseMVA

@@ -1,9 +1,8 @@
 """Environment folder + ``configuration.yaml`` reader (reference: pypownet/parameters.py:10-153).
 
 Same folder layout and the same 17 mandatory scalar keys.  Differences, all additive:
-  * ``loadflow_backend`` additionally accepts ``hip`` (this engine) and ``cpu`` (the CPU oracle, tests only);
-    ``pypower``/``matpower`` are accepted and mapped onto ``hip`` because those runtimes are what this
-    engine replaces;
+  * ``loadflow_backend`` additionally accepts ``hip`` (this engine); ``pypower``/``matpower`` are accepted and mapped
+    onto ``hip`` because those runtimes are what this engine replaces.  There is no CPU backend;
   * optional keys ``solver`` (``newton``|``fdxb``, default ``fdxb`` = the reference's PF_ALG=2), ``tol``,
     ``max_it``;
   * the grid may be ``reference_grid.py`` (PYPOWER case format) or ``reference_grid.json``;
@@ -79,10 +78,10 @@ class Parameters(object):
 
     def get_loadflow_backend(self):
         backend = str(self.simulator_configuration['loadflow_backend']).lower()
-        if backend not in ['matpower', 'pypower', 'hip', 'cpu']:
+        if backend not in ['matpower', 'pypower', 'hip']:
             raise ValueError('loadflow_backend %s is not currently supported; supported backend: '
-                             '"hip", "cpu" ("pypower"/"matpower" map to "hip")' % backend)
-        return 'hip' if backend in ('matpower', 'pypower') else backend
+                             '"hip" ("pypower"/"matpower" map to "hip")' % backend)
+        return 'hip'
 
     def _get_loadflow_mode(self):
         mode = str(self.simulator_configuration['loadflow_mode']).lower()

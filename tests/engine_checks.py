@@ -85,6 +85,24 @@ def check_do_nothing(lib_path, env, solver, steps=12, batch=2):
              check_obs=not (lib_path and 'liboracle' in lib_path))
 
 
+def check_config1_default14_dc(lib_path, steps=1000):
+    """BASELINE.json configs[0] / SURVEY.md 8d config 1: parameters/default14 with loadflow_mode overridden to DC, do-nothing
+    agent, one environment, 1000 timesteps -- the run crosses the end of the first chronic (quirks q1-q3: limits of the
+    first chronic, roll-over skipping row 0, counters kept by reset_grid).  Engine against the numpy restatement."""
+    conf = {'loadflow_mode': 'DC', 'solver': 'fdxb'}
+    eng, case, cfg, chronics = make_engine(lib_path, 'default14', 1, conf=conf)
+    game = oracle_game('default14', conf=conf)
+    eng.reset()
+    compare_state(eng, [game])
+    slots_seen = set()
+    act = np.zeros((1, case.action_length), dtype=np.uint8)
+    for t in range(steps):
+        lockstep(eng, [game], [act], check_obs=(t % 50 == 0) and not (lib_path and 'liboracle' in lib_path))
+        slots_seen.add(int(eng.read('CHRONIC_SLOT')[0]))
+    assert len(slots_seen) >= 2, 'the run must cross a chronic boundary'
+    return slots_seen
+
+
 def check_hard_overflow_scenario(lib_path, solver):
     """K1 consequences (reference tests/test_core.py:968-976, 1423-1427) through the engine."""
     env = 'default14_for_tests_hard_overflow'

@@ -60,6 +60,10 @@ def test_emu_k3_dc(emu_lib):
     ec.check_topology_scenarios(emu_lib, 'default14_for_tests_beta', nodes, 7, _basic_topology_policy)
 
 
+def test_emu_config1_default14_dc_1000_steps(emu_lib):
+    ec.check_config1_default14_dc(emu_lib)
+
+
 def test_emu_default118_few_steps(emu_lib):
     ec.check_do_nothing(emu_lib, 'default118', 'newton', steps=3, batch=1)
 

@@ -68,6 +68,13 @@ def test_gpu_random_actions_vs_c_oracle(env, solver, steps, batch):
     assert st['split_buses'] > 0 and st['illegal'] > 0
 
 
+
+def test_gpu_config1_default14_dc_1000_steps():
+    """BASELINE.json configs[0] through the HIP engine: default14 in DC mode, do-nothing, 1000 timesteps across the end of
+    the first chronic, against the numpy restatement step by step."""
+    ec.check_config1_default14_dc(HIP)
+
+
 def test_gpu_launch_order_does_not_change_results(monkeypatch):
     """The loading-ordered launch (ppn_order_kernel, batches above the 1024 resident slots) only changes WHEN an
     environment runs: every field must be bit-identical with the ordering switched off (PPN_LAUNCH_ORDER=0)."""

@@ -28,6 +28,10 @@ def test_c_oracle_dc(orc):
     ec.check_do_nothing(orc, 'default14_for_tests_beta', 'fdxb', steps=8, batch=1)
 
 
+def test_c_oracle_config1_default14_dc_1000_steps(orc):
+    ec.check_config1_default14_dc(orc)
+
+
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_c_oracle_hard_overflow_scenario(orc, solver):
     ec.check_hard_overflow_scenario(orc, solver)
