@@ -18,8 +18,9 @@ eng.reset(chronic_slot=slots, t0=t0)
 act = np.zeros((B, case.action_length), dtype=np.uint8)
 for _ in range(6):
     eng.step(act, auto_reset=True)
-keys = {'low_vm': [], 'prev_iters': [], 'loading+vm': [], 'loading': [], 'lines_out': [], 'event_next': [], 'loading+event': [], 'loading+out': []}
+keys = {'soft_imminent': [], 'loading+soft': [], 'loading_one_step_old': [], 'low_vm': [], 'prev_iters': [], 'loading+vm': [], 'loading': [], 'lines_out': [], 'event_next': [], 'loading+event': [], 'loading+out': []}
 times = []
+load_prev = np.zeros(B)
 it_prev = eng.read('N_ITERS').astype(np.int64)
 for rep in range(12):
     amps, st = eng.read('AMPS'), eng.read('LINES_STATUS')
@@ -31,6 +32,11 @@ for rep in range(12):
         c = chronics[int(slot[e])]
         r = min(int(row[e]) + 1, c.n_timesteps - 1)
         ev[e] = float((c.maintenance[r] > 0).any() or (c.hazards[r] > 0).any())
+    keys['loading_one_step_old'].append(load_prev.copy()); load_prev = load
+    soft = eng.read('SOFT_COUNT').astype(float)
+    ll = np.nan_to_num(amps / lim[None, :], nan=10.0, posinf=10.0)
+    imm = np.where(ll > 0.97, soft, 0.0).max(axis=1)
+    keys['soft_imminent'].append(imm); keys['loading+soft'].append(load + 0.5 * imm)
     vm, bt = eng.read('VM'), eng.read('BUS_TYPE')
     lowv = -np.where(bt != 4, vm, 9.0).min(axis=1)
     it_now = eng.read('N_ITERS').astype(np.int64)
