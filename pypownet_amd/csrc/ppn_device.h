@@ -86,6 +86,8 @@ __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #define LDS_OR(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
 #endif
 
+// Ybus entries (and, halved, lines) a lane holds in registers in the W-word kernels: 64 * PPN_YPL(W) >= buses + 2 lines
+#define PPN_YPL(W) ((W) == 1 ? 4 : ((W) == 2 ? 8 : 12))
 #define PPN_FILL_REGS 4   // fill-in entries of the Jacobian pattern kept per lane (4 x 64 = 256; beyond that the whole matrix is zeroed)
 #define PPN_NONE 0xFFu     // 'no internal index' in the u8 row -> bus table (max_active_buses <= 254)
 #define PPN_PI 3.14159265358979323846

@@ -607,7 +607,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   e->W = (NB <= 64) ? 1 : (NB <= 128 ? 2 : 4);      // bitset words of the kernel variant (no 3-word build)
   d.YCAP = NB + 2 * nl;
   {
-    const int ypl = (e->W == 1) ? 4 : (e->W == 2 ? 8 : (e->W == 3 ? 10 : 12));   // Ybus entries held per lane (registers)
+    const int ypl = PPN_YPL(e->W);   // Ybus entries held per lane (registers)
     if (d.YCAP > 64 * ypl) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "Ybus of this case (%d entries) exceeds the register budget of the W=%d kernel", d.YCAP, e->W); }
   }
   d.nlev = nlev;
