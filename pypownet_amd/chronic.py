@@ -53,6 +53,23 @@ class TimestepEntries(object):
     def get_datetime(self): return self.datetime
 
 
+_MONTHS = {m: k + 1 for k, m in enumerate(('jan', 'feb', 'mar', 'apr', 'may', 'jun', 'jul', 'aug', 'sep', 'oct', 'nov', 'dec'))}
+_CACHE = {}
+
+
+def load_chronic(source, with_previsions=True):
+    """``Chronic(source)`` through a cache keyed by path and modification time: RunEnv.reset() re-creates the Game like the
+    reference does (environment.py:814-821) and would otherwise re-parse every chronic of the level each time.  The
+    arrays of a cached chronic are shared; nothing in the package writes to them."""
+    key = (os.path.abspath(source), os.path.getmtime(source), bool(with_previsions))
+    c = _CACHE.get(key)
+    if c is None:
+        if len(_CACHE) > 256:
+            _CACHE.clear()
+        c = _CACHE[key] = Chronic(source, with_previsions)
+    return c
+
+
 class Chronic(object):
     """A whole chronic held as dense ``[T x n]`` float32 arrays (the layout uploaded to the GPU)."""
 
@@ -167,8 +184,15 @@ class Chronic(object):
         if self._parsed_dates is None:
             out = np.zeros((self.n_timesteps, 6), dtype=np.int32)
             for r in range(self.n_timesteps):
-                d = datetime.strptime(self.datetimes[r].lower(), '%Y-%b-%d;%H:%M')
-                out[r] = (d.year, d.month, d.day, d.hour, d.minute, d.second)
+                s = self.datetimes[r].lower()
+                try:        # 'YYYY-mon-DD;HH:MM' split by hand (strptime costs 6 us per row, every RunEnv.reset re-reads them)
+                    day, clock = s.split(';')
+                    y, mon, dd = day.split('-')
+                    hh, mm = clock.split(':')
+                    out[r] = (int(y), _MONTHS[mon], int(dd), int(hh), int(mm), 0)
+                except (ValueError, KeyError):
+                    d = datetime.strptime(s, '%Y-%b-%d;%H:%M')
+                    out[r] = (d.year, d.month, d.day, d.hour, d.minute, d.second)
             self._parsed_dates = out
         return self._parsed_dates
 

@@ -11,7 +11,7 @@ import logging
 import numpy as np
 
 from .case import Case
-from .chronic import Chronic, ChronicLooper
+from .chronic import Chronic, ChronicLooper, load_chronic
 from .engine import (Engine, FLAG_DIVERGED, FLAG_TOO_MANY_LOADS, FLAG_TOO_MANY_PRODS, FLAG_ENGINE_CAPACITY,
                      ILL_TOO_MANY, ILL_BROKEN_LINE, ILL_LINE_COOLDOWN, ILL_NODE_COOLDOWN)
 from .parameters import Parameters
@@ -210,7 +210,7 @@ class Game(object):
         n = len(looper.chronics)
         order = [(chronic_starting_id + k) % n for k in range(n)] if chronic_looping_mode == 'natural' \
             else [chronic_starting_id]
-        self._chronics = [Chronic(looper.chronics[k]) for k in order]
+        self._chronics = [load_chronic(looper.chronics[k]) for k in order]
         self.case = Case.from_file(p.get_reference_grid_path())
         self.engine = Engine(self.case, conf, 1, device=device, chronics=self._chronics,
                              without_overflow_cutoff=without_overflow_cutoff, game_over_mode=game_over_mode,

@@ -14,12 +14,15 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 env = RunEnv(os.path.join(ROOT, 'tests', 'golden', 'envs', name), 'level0')
 a = env.action_space.get_do_nothing_action()
 env.step(a)
-t = time.perf_counter()
-n_done = 0
-for _ in range(steps):
-    obs, r, done, flag = env.step(a)
-    if done:
-        n_done += 1
-        env.reset()
-el = time.perf_counter() - t
-print('%s: %d RunEnv.step calls in %.2f s = %.0f steps/s (%d game overs)' % (name, steps, el, steps / el, n_done))
+for how in ('process_game_over', 'reset'):
+    # on a game over the reference's Runner calls process_game_over (runner.py:81-96); reset() re-instantiates the Game
+    # (environment.py:814-821: parameters, case, chronics, engine) and is there for callers that do that instead
+    t = time.perf_counter()
+    n_done = 0
+    for _ in range(steps):
+        obs, r, done, flag = env.step(a)
+        if done:
+            n_done += 1
+            getattr(env, how)()
+    el = time.perf_counter() - t
+    print('%s: %d RunEnv.step calls in %.2f s = %.0f steps/s (%d game overs, each followed by %s())' % (name, steps, el, steps / el, n_done, how))
