@@ -191,11 +191,18 @@ struct Smem {
 
 // Single definition of the LDS layout: carves `base` into S and returns the total size in bytes
 // (call with base == nullptr on the host to size the launch).
-PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp) {
+// compact = true: only what the kernels without a solve touch (observation gather, is_action_valid) -- a few KB instead of
+// the solver's working set, so that all their workgroups are resident at once.
+PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp, bool compact = false) {
   Smem& S = *Sp;
   size_t o = 0;
   const size_t NB = d.NB, nl = d.nl, nrows = d.nrows;
 #define PPN_TAKE(field, type, bytes) S.field = (type*)(base + o); o += (((size_t)(bytes)) + 15) & ~(size_t)15;
+  if (compact) {
+    PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(touched, u8, nrows) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
+    PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
+    return o;
+  }
   // setup group first (overlaid on lu)
   PPN_TAKE(adj0, u64, NB * W * 8) PPN_TAKE(adjF, u64, NB * W * 8)
   PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8)

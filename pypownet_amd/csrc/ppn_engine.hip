@@ -78,6 +78,7 @@ struct ppn_engine {
   std::vector<void*> chronic_allocs;
   hipStream_t stream = 0;
   size_t lds_bytes = 0;
+  size_t lds_small = 0;       // compact carve of the kernels without a solve (K_VALID, K_OBS)
   int base_fill = 0;
   std::string err;
   u8* d_actions = nullptr;
@@ -150,7 +151,7 @@ template <int W, int KIND, int NT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPN_WAVES_PER_EU))) ppn_kernel(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Smem S;
-  ppn_carve(a.d, W, smem, &S);
+  ppn_carve(a.d, W, smem, &S, KIND == K_VALID || KIND == K_OBS);
   const int env = (KIND == K_STEP && a.perm) ? a.perm[blockIdx.x] : (int)blockIdx.x;
   const int lane0 = threadIdx.x;
   if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, lane0);
@@ -217,7 +218,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     (void)hipEventRecord(e0, e->stream);
   }
-  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), e->lds_bytes, e->stream, a);
+  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), (KIND == K_VALID || KIND == K_OBS) ? e->lds_small : e->lds_bytes, e->stream, a);
   if (timed) { (void)hipEventRecord(e1, e->stream); e->launches++; }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
@@ -642,7 +643,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     take(&d.co_fill, (size_t)PPN_FILL_REGS * 64 * 2);   // fill-in entries of the pattern (the ones no Ybus entry covers)
     d.cache_stride = (int)o;
   }
-  { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); }
+  { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); e->lds_small = ppn_carve(d, e->W, nullptr, &tmp, true); }
   if (e->lds_bytes > 160 * 1024) {
     free_all(e); delete e;
     return fail(nullptr, PPN_E_CAPACITY, "case needs %zu bytes of LDS per environment (limit 160 KiB)", e->lds_bytes);
