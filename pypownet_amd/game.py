@@ -336,8 +336,10 @@ class Game(object):
         self.last_action = action
         self.timestep += 1
         eng = self.engine
-        counters = (eng.read('RECONNECTABLE')[0], eng.read('LINE_COOLDOWN')[0], eng.read('NODE_COOLDOWN')[0])
         a = np.asarray(action.as_array())[None, :]
+        # counters as the action meets them: only the payload of an IllegalActionException needs them, and an action
+        # without a switch cannot be illegal
+        counters = (eng.read('RECONNECTABLE')[0], eng.read('LINE_COOLDOWN')[0], eng.read('NODE_COOLDOWN')[0]) if a.any() else None
         if _is_simulation:
             eng.simulate(a)
         else:
