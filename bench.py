@@ -79,7 +79,7 @@ def env_assignment(first, count, chronics):
 def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
     """C oracle (oracle/ppn_oracle.c, OpenMP over environments) on a bounded sample of the same workload."""
     import subprocess
-    from pypownet_amd.engine import Engine
+    from harness import oracle_engine            # tests/harness.py: the checker library is driven from outside the product
     lib = os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')
     if not os.path.exists(lib):
         try:
@@ -88,7 +88,7 @@ def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
             return None
     cores = os.cpu_count() or 1
     nb = max(256, 16 * cores)
-    eng = Engine(case, conf, nb, chronics=chronics, thermal_limits=limits, _lib_path=lib, _lib_prefix='orc_')
+    eng = oracle_engine(case, conf, nb, chronics=chronics, thermal_limits=limits)
     threads = max(1, eng.dim(12))
     slots, t0 = env_assignment(0, nb, chronics)
     eng.reset(chronic_slot=slots, t0=t0)

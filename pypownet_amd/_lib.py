@@ -72,28 +72,18 @@ EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limit
            'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length']
 
 
-class _Prefixed(object):
-    """Attribute view that maps ppn_xxx onto <prefix>xxx (the test-suite drives the C oracle, which exports the
-    same signatures under orc_, through the same harness)."""
-
-    def __init__(self, lib, prefix):
-        self._lib, self._prefix = lib, prefix
-
-    def __getattr__(self, name):
-        if name.startswith('ppn_'):
-            return getattr(self._lib, self._prefix + name[4:])
-        return getattr(self._lib, name)
-
-
-def load_library(path=None, prefix='ppn_'):
-    path = path or os.environ.get('PPN_LIB') or LIB_PATH   # PPN_LIB: experimental builds of the same library
-    if not os.path.exists(path):
+def load_library():
+    """Loads pypownet_amd/libppn.so -- the one and only library of the product path -- and declares its signatures."""
+    if not os.path.exists(LIB_PATH):
         raise ImportError(
             'pypownet_amd: the HIP extension %s is missing. Build it with `python __graft_entry__.py` '
-            '(hipcc --offload-arch=gfx950); this engine has no CPU fallback.' % path)
-    lib = C.CDLL(path)
-    if prefix != 'ppn_':
-        lib = _Prefixed(lib, prefix)
+            '(hipcc --offload-arch=gfx950); this engine has no CPU fallback.' % LIB_PATH)
+    return bind_signatures(C.CDLL(LIB_PATH))
+
+
+def bind_signatures(lib, full_abi=True):
+    """Declares argtypes / restypes of include/ppn.h on a loaded library object (full_abi=False: the subset a checker
+    library of the test-suite exports)."""
     vp = C.c_void_p
     lib.ppn_create.argtypes = [C.POINTER(PpnCase), C.POINTER(PpnRules), C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.ppn_create.restype = C.c_int
@@ -101,7 +91,7 @@ def load_library(path=None, prefix='ppn_'):
     lib.ppn_destroy.restype = C.c_int
     lib.ppn_last_error.argtypes = [vp]
     lib.ppn_last_error.restype = C.c_char_p
-    if prefix == 'ppn_':      # (the C oracle does not compute rewards: oracle/reward_np.py restates them)
+    if full_abi:
         lib.ppn_set_reward.argtypes = [vp, C.POINTER(PpnRewardParams)]
         lib.ppn_set_reward.restype = C.c_int
         lib.ppn_simulate_candidates.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]

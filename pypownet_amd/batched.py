@@ -23,6 +23,14 @@ def shard_range(global_batch, rank, world_size):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def local_device(rank):
+    """GPU of this process: LOCAL_RANK when a launcher set it (one process per GPU of the node), else the rank modulo the
+    number of GPUs of the node (PPN_DEVICES_PER_NODE, default 8)."""
+    if 'LOCAL_RANK' in os.environ:
+        return int(os.environ['LOCAL_RANK'])
+    return int(rank) % max(1, int(os.environ.get('PPN_DEVICES_PER_NODE', '8')))
+
+
 def default_assignment(env_ids, chronics):
     """environment e plays chronic (e mod n) from row (37 e) mod T."""
     env_ids = np.asarray(env_ids)
@@ -33,7 +41,7 @@ def default_assignment(env_ids, chronics):
 
 class BatchedRunEnv(object):
     def __init__(self, parameters_folder, game_level, global_batch, rank=0, world_size=1, device=None,
-                 config_overrides=None, thermal_limits=None, _lib_path=None, _lib_prefix='ppn_', **rule_kw):
+                 config_overrides=None, thermal_limits=None, **rule_kw):
         level = os.path.join(parameters_folder, game_level)
         grid = os.path.join(level, 'reference_grid.py')
         if not os.path.exists(grid):
@@ -50,9 +58,8 @@ class BatchedRunEnv(object):
         self.first, self.last = shard_range(global_batch, rank, world_size)
         self.batch = self.last - self.first
         self.env_ids = np.arange(self.first, self.last)
-        self.engine = Engine(self.case, self.conf, self.batch, device=rank if device is None else device,
-                             chronics=self.chronics, thermal_limits=thermal_limits, _lib_path=_lib_path,
-                             _lib_prefix=_lib_prefix, **rule_kw)
+        self.engine = Engine(self.case, self.conf, self.batch, device=local_device(rank) if device is None else device,
+                             chronics=self.chronics, thermal_limits=thermal_limits, **rule_kw)
         self.action_length = self.case.action_length
         self.observation_length = self.case.observation_length
 

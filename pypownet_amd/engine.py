@@ -54,11 +54,8 @@ def rules_from_conf(conf, without_overflow_cutoff=False, game_over_mode='soft', 
 
 
 class Engine(object):
-    def __init__(self, case, conf, batch, device=0, chronics=None, thermal_limits=None, _lib_path=None,
-                 _lib_prefix='ppn_', **rule_kw):
-        # _lib_path/_lib_prefix exist for the test-suite only (CPU emulation build, C oracle); the product always
-        # loads pypownet_amd/libppn.so and raises if it is missing.
-        self._lib = _lib.load_library(_lib_path, _lib_prefix)
+    def __init__(self, case, conf, batch, device=0, chronics=None, thermal_limits=None, **rule_kw):
+        self._lib = _lib.load_library()     # pypownet_amd/libppn.so; raises ImportError when it has not been built
         self.case = case if isinstance(case, Case) else Case(case)
         self.batch = int(batch)
         self._n_candidates = 0

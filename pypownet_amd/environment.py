@@ -338,7 +338,7 @@ class Observation(MinimalistACObservation):
 class RunEnv(object):
     def __init__(self, parameters_folder, game_level, chronic_looping_mode='natural', start_id=0,
                  game_over_mode='soft', renderer_latency=None, without_overflow_cutoff=False, seed=None, device=0,
-                 config_overrides=None, _lib_path=None, _lib_prefix='ppn_'):
+                 config_overrides=None):
         self.parameters_folder = parameters_folder
         self.game_level = game_level
         self.chronic_looping_mode = chronic_looping_mode
@@ -346,7 +346,7 @@ class RunEnv(object):
         self.game_over_mode = game_over_mode
         self.renderer_latency = renderer_latency
         self.without_overflow_cutoff = without_overflow_cutoff
-        self._extra = dict(device=device, config_overrides=config_overrides, _lib_path=_lib_path, _lib_prefix=_lib_prefix)
+        self._extra = dict(device=device, config_overrides=config_overrides)
         self.game = None
         self.action_space = None
         self.observation_space = None

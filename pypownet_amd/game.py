@@ -180,8 +180,7 @@ class _TopologyView(object):
 
 class Game(object):
     def __init__(self, parameters_folder, game_level, chronic_looping_mode, chronic_starting_id, game_over_mode,
-                 renderer_frame_latency=None, without_overflow_cutoff=False, device=0, config_overrides=None,
-                 _lib_path=None, _lib_prefix='ppn_'):
+                 renderer_frame_latency=None, without_overflow_cutoff=False, device=0, config_overrides=None):
         self.logger = logging.getLogger('pypownet.' + __name__)
         self._parameters = Parameters(parameters_folder, game_level, overrides=config_overrides)
         conf = self._parameters.simulator_configuration
@@ -214,7 +213,7 @@ class Game(object):
         self.case = Case.from_file(p.get_reference_grid_path())
         self.engine = Engine(self.case, conf, 1, device=device, chronics=self._chronics,
                              without_overflow_cutoff=without_overflow_cutoff, game_over_mode=game_over_mode,
-                             looping_mode=chronic_looping_mode, _lib_path=_lib_path, _lib_prefix=_lib_prefix)
+                             looping_mode=chronic_looping_mode)
         self.substations_ids = self.case.sub_ids.astype(float)
         self.grid = self            # agents reach game.grid.get_topology().mapping_array etc.
         self.number_elements_per_substations = list(self.case.n_elements)

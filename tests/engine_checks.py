@@ -6,16 +6,15 @@ import numpy as np
 from helpers import (load_env, oracle_game, do_nothing, set_line_switch, set_substation_switches,
                      nodes_of_substation, differential)
 from oracle.game_np import obs_as_array
+from harness import engine_with_library, ORACLE_LIB
 
 TOL_V = 1e-6      # p.u. / rad: the parity bar of BASELINE.json's north_star
 TOL_FLOW = 1e-4   # MW / MVAr / A
 
 
 def make_engine(lib_path, envname, batch, conf=None, **kw):
-    from pypownet_amd.engine import Engine
     case, cfg, chronics = load_env(envname, conf=conf)
-    prefix = 'orc_' if (lib_path and 'liboracle' in lib_path) else 'ppn_'
-    return Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, _lib_prefix=prefix, **kw), case, cfg, chronics
+    return engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw), case, cfg, chronics
 
 
 def compare_state(eng, games, tol_v=1e-8):
@@ -189,10 +188,9 @@ def check_auto_reset_and_cascade_118(lib_path, steps=25, batch=6, solver='newton
     case, cfg, chronics = load_env('default118', conf={'solver': solver})
     with open(os.path.join(ENVS, 'default118', 'bench_limits.json')) as f:
         limits = np.asarray(json.load(f)['limits_a'])
-    prefix = 'orc_' if (lib_path and 'liboracle' in lib_path) else 'ppn_'
-    mk = lambda lp, pf: Engine(case, cfg, batch, chronics=chronics, thermal_limits=limits, _lib_path=lp, _lib_prefix=pf)
-    a, b = mk(lib_path, prefix), mk(lib_path, prefix)
-    orc = mk(os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'), 'orc_')
+    mk = lambda lp: engine_with_library(lp, case, cfg, batch, chronics=chronics, thermal_limits=limits)
+    a, b = mk(lib_path), mk(lib_path)
+    orc = mk(ORACLE_LIB)
     slots, t0 = default_assignment(np.arange(batch) * 5, chronics)
     for e in (a, b, orc):
         e.reset(chronic_slot=slots, t0=t0)
@@ -247,10 +245,8 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
         cf.update(conf)
     case, cfg, chronics = load_env(envname, conf=cf)
     case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
-    prefix = 'orc_' if (lib_path and 'liboracle' in lib_path) else 'ppn_'
-    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path, _lib_prefix=prefix, **engine_kw)
-    orc = Engine(case, cfg, batch, chronics=chronics, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
-                 _lib_prefix='orc_')
+    eng = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)
+    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics)
     rng = np.random.default_rng(seed)
     eng.reset()
     orc.reset()
@@ -331,9 +327,8 @@ def check_device_reward(lib_path, envname, steps, batch, seed=4321):
     from oracle import reward_np
     case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
     case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
-    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path)
-    orc = Engine(case, cfg, batch, chronics=chronics, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
-                 _lib_prefix='orc_')
+    eng = engine_with_library(lib_path, case, cfg, batch, chronics=chronics)
+    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics)
     k = reward_np.coefficients(case.nS)       # what ppn_create installs (default14: 14, default118: 118)
     rng = np.random.default_rng(seed)
     eng.reset()
@@ -381,9 +376,8 @@ def check_candidate_search(lib_path, envname, batch, n_actions, warm_steps=4, se
     from pypownet_amd.engine import Engine
     case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
     case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
-    eng = Engine(case, cfg, batch, chronics=chronics, _lib_path=lib_path)
-    orc = Engine(case, cfg, batch, chronics=chronics, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
-                 _lib_prefix='orc_')
+    eng = engine_with_library(lib_path, case, cfg, batch, chronics=chronics)
+    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics)
     rng = np.random.default_rng(seed)
     eng.reset()
     orc.reset()

@@ -77,7 +77,15 @@ def test_no_gpu_is_a_loud_error(lib):
     assert 'no HIP device' in str(ei.value) or 'failed' in str(ei.value)
 
 
-def test_missing_extension_raises(tmp_path):
+def test_missing_extension_raises(tmp_path, monkeypatch):
+    """The product loads ONE fixed library path and raises when it is absent (no fallback of any kind)."""
     from pypownet_amd import _lib
+    import inspect
+    assert not inspect.signature(_lib.load_library).parameters      # no way to point the product at another library
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libppn_missing.so'))
     with pytest.raises(ImportError):
-        _lib.load_library(str(tmp_path / 'libppn_missing.so'))
+        _lib.load_library()
+    from pypownet_amd.engine import Engine
+    case, cfg, chronics = load_env('default14_for_tests')
+    with pytest.raises(ImportError):
+        Engine(case, cfg, 1, chronics=chronics)

@@ -15,10 +15,12 @@ import numpy as np
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
 import torch.distributed as dist
 from pypownet_amd.batched import BatchedRunEnv
+import harness
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 dist.init_process_group('gloo', rank=rank, world_size=world)
-env = BatchedRunEnv(%(envdir)r, 'level0', 7, rank=rank, world_size=world, device=0, _lib_path=%(lib)r,
-                    config_overrides={'solver': 'newton'})
+with harness.library(%(lib)r):
+    env = BatchedRunEnv(%(envdir)r, 'level0', 7, rank=rank, world_size=world, device=0,
+                        config_overrides={'solver': 'newton'})
 env.reset()
 for t in range(5):
     obs, done, flag, ill = env.step(np.zeros((env.batch, env.action_length), dtype=np.uint8))
@@ -53,7 +55,9 @@ def test_two_rank_shards_equal_single_process(emu_lib, tmp_path):  # noqa: F811
     for p in procs:
         assert p.wait(timeout=300) == 0
     gathered = np.load(out)
-    single = BatchedRunEnv(envdir, 'level0', 7, device=0, _lib_path=emu_lib, config_overrides={'solver': 'newton'})
+    import harness
+    with harness.library(emu_lib):
+        single = BatchedRunEnv(envdir, 'level0', 7, device=0, config_overrides={'solver': 'newton'})
     single.reset()
     for t in range(5):
         obs, done, flag, ill = single.step(np.zeros((7, single.action_length), dtype=np.uint8))

@@ -12,9 +12,17 @@ from oracle.game_np import obs_as_array
 from test_emu_engine import emu_lib  # noqa: F401  (fixture)
 
 
+@pytest.fixture(autouse=True)
+def _emulation_library(emu_lib):  # noqa: F811
+    """Every RunEnv of this module (and the Game / Engine objects it re-creates on reset()) binds to the emulation build."""
+    import harness
+    with harness.library(emu_lib):
+        yield
+
+
 def make_env(emu_lib, name, **kw):
     from pypownet_amd.environment import RunEnv
-    return RunEnv(os.path.join(ENVS, name), 'level0', _lib_path=emu_lib, **kw)
+    return RunEnv(os.path.join(ENVS, name), 'level0', **kw)
 
 
 def test_obs_roundtrip_and_oracle_match(emu_lib):

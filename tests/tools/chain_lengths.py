@@ -2,13 +2,13 @@
 lasts as long as its longest environment.  Usage: python tests/tools/chain_lengths.py"""
 import os, sys, numpy as np
 ROOT=os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
-sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/tools')
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/tools'); sys.path.insert(0, ROOT+'/tests')
 import bench
-from pypownet_amd.engine import Engine
+from harness import engine_with_library
 lib=os.path.join(ROOT,'build','libppn_prof.so')
 case, conf, chronics = bench.load_workload()
 B=4096
-eng=Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS, _lib_path=lib)
+eng=engine_with_library(lib, case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
 slots,t0=bench.env_assignment(0,B,chronics)
 eng.reset(chronic_slot=slots,t0=t0)
 act=np.zeros((B,case.action_length),dtype=np.uint8)

@@ -20,7 +20,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from helpers import load_env  # noqa: E402
-from pypownet_amd.engine import Engine  # noqa: E402
+from harness import oracle_engine  # noqa: E402
 
 if __name__ == '__main__':
     subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
@@ -28,8 +28,7 @@ if __name__ == '__main__':
     case, conf, chronics = load_env('default118', conf={'solver': 'newton'})
     rows = []
     for slot in range(len(chronics)):
-        eng = Engine(case, conf, 1, chronics=chronics, thermal_limits=np.full(case.nl, 1e9), _lib_path=lib,
-                     _lib_prefix='orc_')
+        eng = oracle_engine(case, conf, 1, chronics=chronics, thermal_limits=np.full(case.nl, 1e9))
         eng.reset(chronic_slot=[slot], t0=[0])
         rows.append(eng.read('AMPS')[0].copy())
         act = np.zeros((1, case.action_length), dtype=np.uint8)

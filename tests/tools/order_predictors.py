@@ -5,14 +5,14 @@ chronic row about to be loaded carries a maintenance or a hazard.  Reported: how
 10 % of the environments sits in the first quarter of the launch order under each key."""
 import os, sys, numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
-sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tools')
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tools'); sys.path.insert(0, ROOT + '/tests')
 import bench
-from pypownet_amd.engine import Engine
+from harness import engine_with_library
 lib = os.path.join(ROOT, 'build', 'libppn_prof.so')
 case, conf, chronics = bench.load_workload()
 B = 4096
 lim = bench.bench_limits(case)
-eng = Engine(case, conf, B, chronics=chronics, thermal_limits=lim, max_active_buses=case.nS, _lib_path=lib)
+eng = engine_with_library(lib, case, conf, B, chronics=chronics, thermal_limits=lim, max_active_buses=case.nS)
 slots, t0 = bench.env_assignment(0, B, chronics)
 eng.reset(chronic_slot=slots, t0=t0)
 act = np.zeros((B, case.action_length), dtype=np.uint8)

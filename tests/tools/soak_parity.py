@@ -11,6 +11,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from pypownet_amd.engine import Engine  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from harness import oracle_engine  # noqa: E402
 
 
 def main():
@@ -20,8 +22,7 @@ def main():
     case, conf, chronics = bench.load_workload()
     lim = bench.bench_limits(case)
     eng = Engine(case, conf, B, chronics=chronics, thermal_limits=lim, max_active_buses=case.nS)
-    orc = Engine(case, conf, B, chronics=chronics, thermal_limits=lim, _lib_path=os.path.join(ROOT, 'oracle', '_build', 'liboracle.so'),
-                 _lib_prefix='orc_')
+    orc = oracle_engine(case, conf, B, chronics=chronics, thermal_limits=lim)
     slots, t0 = bench.env_assignment(0, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
     orc.reset(chronic_slot=slots, t0=t0)

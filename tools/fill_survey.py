@@ -3,7 +3,7 @@
 Drives random RandomNodeSplitting-style actions (reference pypownet/agent.py:116-158) for many steps and reports the
 largest filled pattern / record counts any schedule rebuild produced, next to the capacities ppn_create derived.
 
-  python tools/fill_survey.py [batch] [steps] [p_split]      [single]   (GPU box; PPN_LIB=build/libppn_emu.so runs it on the CPU emulation)
+  python tools/fill_survey.py [batch] [steps] [p_split]      [single]   (GPU box)
 """
 import os
 import sys

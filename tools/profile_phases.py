@@ -19,8 +19,7 @@ NAMES = ['live buses/types/connectivity', 'schedule check (+rebuild)', '(unused)
 
 def main():
     import bench
-    from pypownet_amd.engine import Engine
-    from pypownet_amd import _lib
+    from harness import engine_with_library      # (tests/harness.py: the profiling build is not the product library)
     lib = os.path.join(ROOT, 'build', 'libppn_prof.so')
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     if not os.path.exists(lib) or os.environ.get('PPN_REBUILD'):
@@ -30,8 +29,8 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     split = len(sys.argv) > 3 and sys.argv[3] == 'split'     # random node-splitting actions, every busbar may be active
     case, conf, chronics = bench.load_workload()
-    eng = Engine(case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case),
-                 max_active_buses=(int(sys.argv[4]) if len(sys.argv) > 4 else 2 * case.nS) if split else case.nS, _lib_path=lib)
+    eng = engine_with_library(lib, case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case),
+                              max_active_buses=(int(sys.argv[4]) if len(sys.argv) > 4 else 2 * case.nS) if split else case.nS)
     slots, t0 = bench.env_assignment(0, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
     act = np.zeros((B, case.action_length), dtype=np.uint8)
