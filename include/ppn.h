@@ -56,7 +56,17 @@ enum {
 
 enum { PPN_MODE_AC = 0, PPN_MODE_DC = 1 };
 enum { PPN_SOLVER_NEWTON = 1, PPN_SOLVER_FDXB = 2 };     /* = PYPOWER PF_ALG values (grid.py:63) */
-enum { PPN_LOOP_NATURAL = 0, PPN_LOOP_FIXED = 1 };       /* chronic looping (chronic.py:286-291) */
+enum { PPN_LOOP_NATURAL = 0, PPN_LOOP_FIXED = 1, PPN_LOOP_RANDOM = 2 };   /* chronic looping (chronic.py:266-291) */
+/* PPN_LOOP_RANDOM: the reference draws the next chronic with np.random.choice on the host (chronic.py:283-289).  Here every
+ * environment draws it on the device from a counter-based generator: slot = ppn_mix32(rng_seed, env, draw) % n_slots, draw =
+ * number of chronics this environment has drawn so far (uniform like the reference's, reproducible under rng_seed, not the
+ * same stream as numpy's). */
+/* what happened to a line during the last step (PPN_F_LINE_EVENTS): the events the reference logs line by line,
+ * game.py:436-469 (maintenance / hazards), 541-578 (overflow cuts), 627-648 (agent switches) */
+enum { PPN_EV_SWITCHED = 1, PPN_EV_MAINTENANCE = 2, PPN_EV_HAZARD = 4, PPN_EV_HARD_OVERFLOW = 8, PPN_EV_SOFT_OVERFLOW = 16 };
+/* outcome of the last load-flow solve of the step's cascade (PPN_F_SOLVE_OUTCOME): which text the reference's
+ * DivergingLoadflowException carries, grid.py:231, 238 ('The grid is not connexe') vs grid.py:264 ('Power grid outage') */
+enum { PPN_SOLVE_CONVERGED = 0, PPN_SOLVE_OUTAGE = 1, PPN_SOLVE_NOT_CONNEXE = 2, PPN_SOLVE_CAPACITY = 4 };
 
 /* The case: MATPOWER-v2 arrays exactly as `loadcase` returns them (reference grid.py:65), float64 row-major.
  * bus: [2*nS x bus_cols>=13], gen: [nP x gen_cols>=8], branch: [nl x branch_cols>=11]. */
@@ -95,6 +105,7 @@ typedef struct ppn_rules {
    * topology that exceeds a capacity reports PPN_FLAG_ENGINE_CAPACITY for that environment. */
   int32_t max_active_buses;
   int32_t lu_capacity;                /* doubles of LU storage per environment, 0 = auto */
+  int32_t rng_seed;                   /* PPN_LOOP_RANDOM: seed of the per-environment chronic draws */
 } ppn_rules;
 
 /* One chronic as parsed by the reference reader (pypownet/chronic.py:173-229): float32 [T x n] row-major,
@@ -155,6 +166,9 @@ typedef enum ppn_field {
                                         line switches, on-cooldown substations (game.py:650-753)                         */
   PPN_F_ACTION_SWITCHES,   /* i32 [2]   node switches, line-status switches of the action as the caller sees it after the
                                         step: repaired in place, zeroed when the whole action was rejected (game.py:813)  */
+  PPN_F_LINE_EVENTS,       /* u8 [nl]   PPN_EV_* bits: what happened to each line during the last step (the restart of an
+                                        episode that ended is not part of it)                                            */
+  PPN_F_SOLVE_OUTCOME,     /* i32 [1]   PPN_SOLVE_*: outcome of the last solve of the last step's cascade                 */
   PPN_F_COUNT
 } ppn_field;
 

@@ -67,8 +67,10 @@ typedef struct {
 
 typedef struct {
   double *vm, *va, *pg, *qg, *vg, *pd, *qd, *pf, *qf, *pt, *qt, *amps;
-  uint8_t *pn, *ln, *on, *en, *st, *btype;
+  uint8_t *pn, *ln, *on, *en, *st, *btype, *lev;
   int *rec, *lcd, *ncd, *soft;
+  int id, src;      /* index of the environment (seed of its chronic draws), outcome of the last solve of the step's cascade */
+  unsigned draws;   /* chronics drawn so far (PPN_LOOP_RANDOM) */
   int done, dead, succ, flag, ill, depth, nsolve, niter, slot, row, nlc, npc, epoch;
   int illn[3], actsw[2];   /* IllegalActionException contents as counts; node / line switches of the action after the step */
   double min_vm;    /* test diagnostic: smallest |V| of an active bus over the solves of the last step (the last
@@ -522,14 +524,26 @@ done:
 /* ------------------------------------------------------------------------------------------------------ */
 static int flag_of(int rc) { return rc == 0 ? 0 : (rc == 4 ? 4 : 1); }
 
-static void orc_advance(const OCase* c, OEnv* e, int sim) {
+/* counter-based generator of the chronic draws: the function include/ppn.h specifies for PPN_LOOP_RANDOM */
+static unsigned mix32(unsigned seed, unsigned env, unsigned draw) {
+  unsigned h = seed * 0x9E3779B1u ^ (env + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (draw + 1u) * 0xC2B2AE35u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return h;
+}
+static int next_slot(const OCase* c, OEnv* e) {      /* chronic.py:283-291 */
+  if (c->R.chronic_looping == PPN_LOOP_FIXED) return e->slot;
+  if (c->R.chronic_looping == PPN_LOOP_RANDOM) return (int)(mix32((unsigned)c->R.rng_seed, (unsigned)e->id, e->draws++) % (unsigned)c->n_slots);
+  return (e->slot + 1) % c->n_slots;
+}
+
+static void orc_advance(const OCase* c, OEnv* e, int sim, int rec_ev) {
   const int nP = c->nP, nL = c->nL, nl = c->nl, nS = c->nS;
   int slot = e->slot, row = e->row;
   const int cur_slot = slot, cur_row = row < 0 ? 0 : row;
   int T = c->cT[slot];
   if (row == T - 1 && !sim) {
     /* roll-over with quirk q2 (game.py:481-493) */
-    const int next = (c->R.chronic_looping == PPN_LOOP_FIXED) ? slot : (slot + 1) % c->n_slots;
+    const int next = next_slot(c, e);
     int i0 = 0; for (int k = 0; k < T; ++k) if (c->ids[slot][k] == 0) { i0 = k; break; }
     const int nid = c->ids[slot][(i0 + 1 < T) ? i0 + 1 : T - 1];
     int r = -1; for (int k = 0; k < c->cT[next]; ++k) if (c->ids[next][k] == nid) { r = k; break; }
@@ -553,13 +567,13 @@ static void orc_advance(const OCase* c, OEnv* e, int sim) {
   const float* mt = c->mt[slot] + (size_t)row * nl;
   const float* hz = c->hz[slot] + (size_t)row * nl;
   for (int l = 0; l < nl; ++l) {
-    if (mt[l] > 0.0f) { e->st[l] = 0; if ((int)mt[l] > e->rec[l]) e->rec[l] = (int)mt[l]; }
-    if (!sim && hz[l] > 0.0f) { e->st[l] = 0; if ((int)hz[l] > e->rec[l]) e->rec[l] = (int)hz[l]; }
+    if (mt[l] > 0.0f) { e->st[l] = 0; if ((int)mt[l] > e->rec[l]) e->rec[l] = (int)mt[l]; if (rec_ev) e->lev[l] |= PPN_EV_MAINTENANCE; }
+    if (!sim && hz[l] > 0.0f) { e->st[l] = 0; if ((int)hz[l] > e->rec[l]) e->rec[l] = (int)hz[l]; if (rec_ev) e->lev[l] |= PPN_EV_HAZARD; }
   }
   e->slot = slot; e->row = row;
 }
 
-static int orc_cascade(const OCase* c, OEnv* e) {
+static int orc_cascade(const OCase* c, OEnv* e, int rec_ev) {
   const int nl = c->nl;
   char* over = (char*)calloc(nl, 1);
   int solves = 0, rc = 0;
@@ -573,14 +587,17 @@ static int orc_cascade(const OCase* c, OEnv* e) {
     if (!nover) break;
     for (int l = 0; l < nl; ++l) if (over[l] && e->amps[l] > c->R.hard_overflow_coefficient * c->limits[l]) {
       e->st[l] = 0; e->rec[l] = c->R.n_timesteps_hard_overflow_is_broken; over[l] = 0; cut = 1;
+      if (rec_ev) e->lev[l] |= PPN_EV_HARD_OVERFLOW;
     }
     for (int l = 0; l < nl; ++l) if (over[l] && (double)e->soft[l] >= c->R.n_timesteps_consecutive_soft_overflow_breaks) {
       e->st[l] = 0; e->rec[l] = c->R.n_timesteps_soft_overflow_is_broken; over[l] = 0; cut = 1;
+      if (rec_ev) e->lev[l] |= PPN_EV_SOFT_OVERFLOW;
     }
     if (!cut) break;
   }
   if (!rc) for (int l = 0; l < nl; ++l) e->soft[l] = over[l] ? e->soft[l] + 1 : 0;
   e->depth = solves - 1; e->nsolve += solves; e->succ = (rc == 0);
+  if (rec_ev) e->src = rc;
   free(over);
   return rc;
 }
@@ -627,6 +644,7 @@ static int orc_apply_action(const OCase* c, OEnv* e, const uint8_t* action, int 
     }
   }
   if (apply) { e->illn[0] = nb; e->illn[1] = nc; e->illn[2] = nn; e->actsw[0] = swn; e->actsw[1] = swl; }
+  if (apply) for (int l = 0; l < nl; ++l) e->lev[l] = a[ntopo + l] ? PPN_EV_SWITCHED : 0;     /* events of this step start here */
   if (apply) {
     for (int g = 0; g < nP; ++g) if (a[g]) e->pn[g] ^= 1;
     for (int q = 0; q < nL; ++q) if (a[nP + q]) e->ln[q] ^= 1;
@@ -652,8 +670,8 @@ static void orc_step_env(const OCase* c, OEnv* e, const uint8_t* action, int sim
   e->min_vm = 1e300;
   if (e->dead) return;
   const int ill = orc_apply_action(c, e, action, 1);
-  orc_advance(c, e, sim);
-  const int rc = orc_cascade(c, e);
+  orc_advance(c, e, sim, 1);
+  const int rc = orc_cascade(c, e, 1);
   int flag = flag_of(rc);
   if (!flag) flag = orc_cut_flags(c, e);
   e->flag = flag; e->ill = ill; e->done = flag != 0; e->dead = flag != 0;
@@ -665,13 +683,13 @@ static void orc_game_over_env(const OCase* c, OEnv* e, int force) {
   for (int attempt = 0; attempt < 64; ++attempt) {
     orc_reset_grid(c, e);
     if (c->R.game_over_mode_hard) {
-      const int slot = (c->R.chronic_looping == PPN_LOOP_FIXED) ? e->slot : (e->slot + 1) % c->n_slots;
+      const int slot = next_slot(c, e);
       int j0 = 0; for (int k = 0; k < c->cT[slot]; ++k) if (c->ids[slot][k] == 0) { j0 = k; break; }
       e->slot = slot; e->row = ((j0 + 1 < c->cT[slot]) ? j0 + 1 : c->cT[slot] - 1) - 1;
     }
     e->epoch++;
-    orc_advance(c, e, 0);
-    rc = orc_cascade(c, e);
+    orc_advance(c, e, 0, 0);
+    rc = orc_cascade(c, e, 0);
     if (rc == 0 || rc == 4) break;
   }
   orc_cut_flags(c, e);
@@ -686,7 +704,7 @@ static void env_alloc(const OCase* c, OEnv* e) {
 #define N(n) (int*)calloc((n) > 0 ? (n) : 1, sizeof(int))
   e->vm = D(c->nrows); e->va = D(c->nrows); e->pg = D(c->nP); e->qg = D(c->nP); e->vg = D(c->nP); e->pd = D(c->nL); e->qd = D(c->nL);
   e->pf = D(c->nl); e->qf = D(c->nl); e->pt = D(c->nl); e->qt = D(c->nl); e->amps = D(c->nl);
-  e->pn = U(c->nP); e->ln = U(c->nL); e->on = U(c->nl); e->en = U(c->nl); e->st = U(c->nl); e->btype = U(c->nrows);
+  e->pn = U(c->nP); e->ln = U(c->nL); e->on = U(c->nl); e->en = U(c->nl); e->st = U(c->nl); e->btype = U(c->nrows); e->lev = U(c->nl);
   e->rec = N(c->nl); e->lcd = N(c->nl); e->ncd = N(c->nS); e->soft = N(c->nl);
 #undef D
 #undef U
@@ -698,8 +716,9 @@ static void env_copy(const OCase* c, OEnv* d, const OEnv* s) {
   CP(pd, c->nL, double) CP(qd, c->nL, double) CP(pf, c->nl, double) CP(qf, c->nl, double) CP(pt, c->nl, double)
   CP(qt, c->nl, double) CP(amps, c->nl, double) CP(pn, c->nP, uint8_t) CP(ln, c->nL, uint8_t) CP(on, c->nl, uint8_t)
   CP(en, c->nl, uint8_t) CP(st, c->nl, uint8_t) CP(btype, c->nrows, uint8_t) CP(rec, c->nl, int) CP(lcd, c->nl, int)
-  CP(ncd, c->nS, int) CP(soft, c->nl, int)
+  CP(ncd, c->nS, int) CP(soft, c->nl, int) CP(lev, c->nl, uint8_t)
 #undef CP
+  d->id = s->id; d->src = s->src; d->draws = s->draws;
   d->done = s->done; d->dead = s->dead; d->succ = s->succ; d->flag = s->flag; d->ill = s->ill; d->depth = s->depth;
   d->nsolve = s->nsolve; d->niter = s->niter; d->slot = s->slot; d->row = s->row; d->nlc = s->nlc; d->npc = s->npc; d->epoch = s->epoch;
 }
@@ -762,7 +781,7 @@ int orc_create(const ppn_case* pc, const ppn_rules* r, int32_t batch, int32_t de
   c->limits = (double*)malloc(nl * 8); for (int l = 0; l < nl; ++l) c->limits[l] = 1e30;
   E->batch = batch;
   E->env = (OEnv*)calloc(batch, sizeof(OEnv)); E->sim = (OEnv*)calloc(batch, sizeof(OEnv));
-  for (int b = 0; b < batch; ++b) { env_alloc(c, &E->env[b]); env_alloc(c, &E->sim[b]); }
+  for (int b = 0; b < batch; ++b) { env_alloc(c, &E->env[b]); env_alloc(c, &E->sim[b]); E->env[b].id = b; E->sim[b].id = b; }
   *out = E;
   return PPN_OK;
 }
@@ -803,8 +822,9 @@ int orc_reset(orc_engine* E, const int32_t* env_ids, int32_t n, const int32_t* s
     for (int l = 0; l < c->nl; ++l) { e->soft[l] = 0; e->amps[l] = 0; }
     for (int g = 0; g < c->nP; ++g) { e->pg[g] = 0; e->qg[g] = c->qg0[g]; e->vg[g] = 0; }
     e->slot = slots ? slots[k] : 0; e->row = (t0 ? t0[k] : 0) - 1; e->epoch = 1; e->nsolve = 0; e->niter = 0;
-    orc_advance(c, e, 0);
-    const int rc = orc_cascade(c, e);
+    memset(e->lev, 0, c->nl);
+    orc_advance(c, e, 0, 1);
+    const int rc = orc_cascade(c, e, 1);
     orc_cut_flags(c, e);
     e->flag = flag_of(rc); e->ill = 0; e->done = e->flag != 0; e->dead = e->done;
   }
@@ -861,6 +881,7 @@ static int field_ptr(const OCase* c, OEnv* e, ppn_field f, void** p, size_t* byt
     case PPN_F_NODE_COOLDOWN: A(e->ncd, c->nS, int) case PPN_F_SOFT_COUNT: A(e->soft, c->nl, int)
     case PPN_F_FLAG: S(e->flag) case PPN_F_ILLEGAL: S(e->ill) case PPN_F_CASCADE_DEPTH: S(e->depth)
     case PPN_F_ILLEGAL_COUNTS: A(e->illn, 3, int) case PPN_F_ACTION_SWITCHES: A(e->actsw, 2, int)
+    case PPN_F_LINE_EVENTS: A(e->lev, c->nl, uint8_t) case PPN_F_SOLVE_OUTCOME: S(e->src)
     case PPN_F_N_SOLVES: S(e->nsolve) case PPN_F_N_ITERS: S(e->niter) case PPN_F_CHRONIC_SLOT: S(e->slot)
     case PPN_F_CHRONIC_ROW: S(e->row) case PPN_F_N_LOADS_CUT: S(e->nlc) case PPN_F_N_PRODS_CUT: S(e->npc)
     default: return -1;

@@ -36,7 +36,8 @@ class PpnRules(C.Structure):
                 ('n_timesteps_actionned_node_reactionable', C.c_int32),
                 ('max_number_actionned_substations', C.c_int32), ('max_number_actionned_lines', C.c_int32),
                 ('max_number_actionned_total', C.c_int32), ('game_over_mode_hard', C.c_int32),
-                ('chronic_looping', C.c_int32), ('max_active_buses', C.c_int32), ('lu_capacity', C.c_int32)]
+                ('chronic_looping', C.c_int32), ('max_active_buses', C.c_int32), ('lu_capacity', C.c_int32),
+                ('rng_seed', C.c_int32)]
 
 
 class PpnChronic(C.Structure):
@@ -51,10 +52,11 @@ FIELDS = ['VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMP
           'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN',
           'SOFT_COUNT', 'DONE', 'FLAG', 'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT',
           'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE', 'REWARD', 'ILLEGAL_COUNTS',
-          'ACTION_SWITCHES']
+          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME']
 FIELD_ID = {k: i for i, k in enumerate(FIELDS)}
 _F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD'}
-_U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE'}
+_U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE',
+       'LINE_EVENTS'}
 
 
 def field_dtype(name):

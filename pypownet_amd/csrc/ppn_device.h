@@ -104,6 +104,7 @@ struct DevRules {
   int n_line_cooldown, n_node_cooldown;
   int max_subs, max_lines, max_total;
   int hard_mode;
+  int loop_mode; unsigned seed;   // chronic looping (PPN_LOOP_*), seed of the per-environment chronic draws (PPN_LOOP_RANDOM)
   double rw[13];     // ppn_reward_params, in declaration order
 };
 
@@ -142,6 +143,7 @@ struct DevCase {
   int n_slots;
   const float *c_pp, *c_pv, *c_lp, *c_lq, *c_ppp, *c_pvp, *c_lpp, *c_lqp, *c_mt, *c_hz;
   const int *c_off, *c_T, *c_next, *c_roll, *c_restart;
+  const int* c_roll2;    // [n_slots x n_slots] row loaded first when the chronic `old` rolls over into `new` (quirk q2), any pair
   const int *c_dates;    // [rows x 6]
   DevRules R;
 };
@@ -156,6 +158,11 @@ struct DevState {
   int *rec, *lcd, *ncd, *soft;     // counters
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
+  u8* lev;                         // [nl] PPN_EV_* bits of the last step
+  int* src;                        // outcome (SOLVE_*) of the last solve of the last step's cascade
+  unsigned* draws;                 // chronics drawn so far by this environment (PPN_LOOP_RANDOM)
+  int* prow;                       // absolute chronic row whose planned_* series the observation shows: the row just loaded, or -- in a
+                                   // simulation -- the row the simulation STARTED from (game.py:410-413: simulate does not advance the entries)
   long long* prof;                 // [32] cycle counters per phase (only written by -DPPN_PROF builds)
   double* reward;                  // [5] reward components of the last step
   int *illn, *actsw;               // [3] illegal-action counts, [2] node / line switches of the action after the step
@@ -188,6 +195,13 @@ struct Smem {
 #else
 #define PPN_HD __host__ __device__ __forceinline__
 #endif
+
+// counter-based generator of the chronic draws (include/ppn.h, PPN_LOOP_RANDOM)
+PPN_HD unsigned ppn_mix32(unsigned seed, unsigned env, unsigned draw) {
+  unsigned h = seed * 0x9E3779B1u ^ (env + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (draw + 1u) * 0xC2B2AE35u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return h;
+}
 
 // Single definition of the LDS layout: carves `base` into S and returns the total size in bytes
 // (call with base == nullptr on the host to size the launch).

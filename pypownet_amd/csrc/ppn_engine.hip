@@ -69,6 +69,7 @@ struct ppn_engine {
   std::vector<void*> allocs;
   std::vector<HostChronic> chronics;
   bool chronics_dirty = true;
+  bool mem_failed = false;    // sticky: a device allocation or an upload failed (checked by the entry point that caused it)
   bool newton = false;        // rules: AC mode with the Newton-Raphson solver -> the NT = 1 kernels
   bool maybe_dead = true;     // some environment may be over at the next ppn_step (see ppn_step)
   // shared schedule of the reference topology (DevCase::b_*): allocated by ppn_create, filled from the first environment
@@ -76,6 +77,7 @@ struct ppn_engine {
   u8* base_cache = nullptr; u64 *base_tri = nullptr, *base_pair = nullptr; unsigned* base_piv = nullptr;
   bool base_ready = false;
   std::vector<void*> chronic_allocs;
+  std::vector<void*> cand_allocs;     // candidate slots of ppn_simulate_candidates (released when they are outgrown)
   hipStream_t stream = 0;
   size_t lds_bytes = 0;
   size_t lds_small = 0;       // compact carve of the kernels without a solve (K_VALID, K_OBS)
@@ -112,18 +114,18 @@ static int fail(ppn_engine* e, int code, const char* fmt, ...) {
 template <typename T>
 static T* upload(ppn_engine* e, const std::vector<T>& v, std::vector<void*>& pool) {
   void* p = nullptr;
-  if (dev_malloc(&p, v.size() * sizeof(T) + 16)) return nullptr;
+  if (dev_malloc(&p, v.size() * sizeof(T) + 16)) { e->mem_failed = true; return nullptr; }
   pool.push_back(p);
-  if (!v.empty()) dev_h2d(p, v.data(), v.size() * sizeof(T), e->stream);
+  if (!v.empty() && dev_h2d(p, v.data(), v.size() * sizeof(T), e->stream)) e->mem_failed = true;
   return (T*)p;
 }
 
 template <typename T>
 static T* dalloc(ppn_engine* e, size_t n) {
   void* p = nullptr;
-  if (dev_malloc(&p, n * sizeof(T) + 16)) return nullptr;
+  if (dev_malloc(&p, n * sizeof(T) + 16)) { e->mem_failed = true; return nullptr; }
   e->allocs.push_back(p);
-  dev_zero(p, n * sizeof(T), e->stream);
+  if (dev_zero(p, n * sizeof(T), e->stream)) e->mem_failed = true;
   return (T*)p;
 }
 
@@ -331,7 +333,8 @@ extern "C" const char* ppn_last_error(const ppn_engine* e) { return e ? e->err.c
 static void free_all(ppn_engine* e) {
   for (void* p : e->allocs) dev_free(p);
   for (void* p : e->chronic_allocs) dev_free(p);
-  e->allocs.clear(); e->chronic_allocs.clear();
+  for (void* p : e->cand_allocs) dev_free(p);
+  e->allocs.clear(); e->chronic_allocs.clear(); e->cand_allocs.clear();
 #ifndef PPN_EMU
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -362,13 +365,14 @@ static int alloc_state(ppn_engine* e, DevState* s, size_t B) {
   s->flag = dalloc<int>(e, B); s->ill = dalloc<int>(e, B); s->depth = dalloc<int>(e, B);
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
+  s->prow = dalloc<int>(e, B); s->lev = dalloc<u8>(e, B * d.nl); s->src = dalloc<int>(e, B); s->draws = dalloc<unsigned>(e, B);
   s->prof = dalloc<long long>(e, B * 32);
   s->prio = dalloc<float>(e, B);
   s->reward = dalloc<double>(e, B * 5); s->illn = dalloc<int>(e, B * 3); s->actsw = dalloc<int>(e, B * 2);
   s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
   s->ws_piv = dalloc<unsigned>(e, B * d.NB);
   s->ws_cache = dalloc<u8>(e, B * (size_t)d.cache_stride);   // zero-filled: header.valid == 0
-  return (s->ws_piv && s->ws_cache) ? 0 : -1;
+  return e->mem_failed ? -1 : 0;     // (every dalloc above records its failure)
 }
 
 struct FieldInfo { size_t elem; int n; size_t off; };   // off: byte offset of the pointer inside DevState
@@ -419,6 +423,8 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
     case PPN_F_REWARD: FI(reward, double, 5, false)
     case PPN_F_ILLEGAL_COUNTS: FI(illn, int, 3, false)
     case PPN_F_ACTION_SWITCHES: FI(actsw, int, 2, false)
+    case PPN_F_LINE_EVENTS: FI(lev, u8, d.nl, false)
+    case PPN_F_SOLVE_OUTCOME: FI(src, int, 1, false)
     default: return false;
   }
 #undef FI
@@ -680,6 +686,8 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   R.n_node_cooldown = r->n_timesteps_actionned_node_reactionable;
   R.max_subs = r->max_number_actionned_substations; R.max_lines = r->max_number_actionned_lines;
   R.max_total = r->max_number_actionned_total; R.hard_mode = r->game_over_mode_hard;
+  R.loop_mode = r->chronic_looping; R.seed = (unsigned)r->rng_seed;
+  if (R.loop_mode != PPN_LOOP_NATURAL && R.loop_mode != PPN_LOOP_FIXED && R.loop_mode != PPN_LOOP_RANDOM) return bad("chronic_looping must be PPN_LOOP_NATURAL, _FIXED or _RANDOM");
   default_reward(R.rw, (double)nS);
   if (R.solver != PPN_SOLVER_NEWTON && R.solver != PPN_SOLVER_FDXB) return bad("solver must be NEWTON or FDXB");
   if (R.max_it <= 0) R.max_it = (R.solver == PPN_SOLVER_NEWTON) ? 10 : 25;
@@ -688,14 +696,14 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (alloc_state(e, &e->st, (size_t)batch) || alloc_state(e, &e->sim, (size_t)batch)) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
   e->base_cache = dalloc<u8>(e, (size_t)d.cache_stride); e->base_tri = dalloc<u64>(e, (size_t)d.TCAP);
   e->base_pair = dalloc<u64>(e, (size_t)d.MCAP); e->base_piv = dalloc<unsigned>(e, (size_t)d.NB);
-  if (!e->base_cache || !e->base_tri || !e->base_pair || !e->base_piv) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
+  if (e->mem_failed) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
   e->d_actions = dalloc<u8>(e, (size_t)batch * d.alen);
   e->d_valid = dalloc<u8>(e, batch);
   e->d_perm = dalloc<int>(e, batch);
   { const char* v = getenv("PPN_LAUNCH_ORDER"); if (v && v[0] == '0') e->order_launches = false; }
   e->d_ids = dalloc<int>(e, (size_t)3 * batch);
   e->d_obs = dalloc<double>(e, (size_t)batch * d.obslen);
-  if (!e->d_obs) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
+  if (e->mem_failed) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation or upload failed: %s", dev_err()); }
 #ifndef PPN_EMU
   int rc_attr = 0;
   switch (e->W) { case 1: rc_attr = set_lds_attr<1>(e->lds_bytes); break; case 2: rc_attr = set_lds_attr<2>(e->lds_bytes); break;
@@ -743,7 +751,7 @@ static int sync_chronics(ppn_engine* e) {
   for (void* p : e->chronic_allocs) dev_free(p);
   e->chronic_allocs.clear();
   const int ns = (int)e->chronics.size();
-  std::vector<int> off(ns), T(ns), next(ns), roll(ns), restart(ns), dates;
+  std::vector<int> off(ns), T(ns), next(ns), roll(ns), restart(ns), roll2((size_t)ns * ns), dates;
   std::vector<float> pp, pv, lp, lq, ppp, pvp, lpp, lqp, mt, hz;
   int rows = 0;
   for (int s = 0; s < ns; ++s) {
@@ -764,6 +772,11 @@ static int sync_chronics(ppn_engine* e) {
     int nid = old_.ids[std::min(std::max(i0, 0) + 1, old_.T - 1)];
     int r_ = index_of(nw.ids, nid);
     roll[s] = r_ < 0 ? std::min(1, nw.T - 1) : r_;
+    for (int s2 = 0; s2 < ns; ++s2) {       // the same rule for any successor (PPN_LOOP_RANDOM)
+      const HostChronic& n2 = e->chronics[s2];
+      const int r2 = index_of(n2.ids, nid);
+      roll2[(size_t)s * ns + s2] = r2 < 0 ? std::min(1, n2.T - 1) : r2;
+    }
     // hard game over (game.py:770-776): current id None -> get_next_chronic() (id 0) -> next id of the new chronic
     const HostChronic& me = e->chronics[s];
     int j0 = index_of(me.ids, 0);
@@ -779,7 +792,8 @@ static int sync_chronics(ppn_engine* e) {
   d.c_off = upload(e, off, e->chronic_allocs); d.c_T = upload(e, T, e->chronic_allocs);
   d.c_next = upload(e, next, e->chronic_allocs); d.c_roll = upload(e, roll, e->chronic_allocs);
   d.c_restart = upload(e, restart, e->chronic_allocs); d.c_dates = upload(e, dates, e->chronic_allocs);
-  if (!d.c_dates) return fail(e, PPN_E_HIP, "chronic upload failed: %s", dev_err());
+  d.c_roll2 = upload(e, roll2, e->chronic_allocs);
+  if (e->mem_failed) { e->mem_failed = false; return fail(e, PPN_E_HIP, "chronic upload failed: %s", dev_err()); }
   e->chronics_dirty = false;
   return PPN_OK;
 }
@@ -849,7 +863,7 @@ static int copy_state(ppn_engine* e, DevState* dst, const DevState* src) {
   CP(st, u8, d.nl) CP(rec, int, d.nl) CP(lcd, int, d.nl) CP(ncd, int, d.nS) CP(soft, int, d.nl)
   CP(done, u8, 1) CP(dead, u8, 1) CP(succ, u8, 1) CP(btype, u8, d.nrows) CP(flag, int, 1) CP(ill, int, 1)
   CP(depth, int, 1) CP(nsolve, int, 1) CP(niter, int, 1) CP(slot, int, 1) CP(row, int, 1) CP(nlc, int, 1)
-  CP(npc, int, 1) CP(epoch, int, 1)
+  CP(npc, int, 1) CP(epoch, int, 1) CP(prow, int, 1) CP(lev, u8, d.nl) CP(src, int, 1) CP(draws, unsigned, 1)
 #undef CP
   return rc;
 }
@@ -860,6 +874,7 @@ static void default_reward(double* rw, double c) {   // parameters/default14/rew
 }
 
 extern "C" int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p) {
+  enter(e);
   if (!e || !p) return PPN_E_INVALID;
   const double* v = (const double*)p;
   for (int k = 0; k < 13; ++k) e->dc.R.rw[k] = v[k];
@@ -929,13 +944,27 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
   for (int c = 0; c < n; ++c) if (env_ids[c] < 0 || env_ids[c] >= e->batch) return fail(e, PPN_E_INVALID, "ppn_simulate_candidates: environment %d out of range", env_ids[c]);
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
   const DevCase& d = e->dc;
-  if (n > e->cand_cap) {      // (re)allocate the candidate slots; earlier slots are released with the engine
+  if (n > e->cand_cap) {      // (re)allocate the candidate slots; the outgrown ones are released first
     const int cap = std::max(n, std::max(e->batch, 2 * e->cand_cap));
-    if (alloc_state(e, &e->cand, (size_t)cap)) return fail(e, PPN_E_HIP, "candidate slots: device allocation failed: %s", dev_err());
+#ifndef PPN_EMU
+    (void)hipStreamSynchronize(e->stream);     // nothing in flight may still read the old slots
+#endif
+    for (void* p : e->cand_allocs) dev_free(p);
+    e->cand_allocs.clear();
+    e->cand_cap = 0; e->n_cand = 0;
+    const size_t mark = e->allocs.size();
+    alloc_state(e, &e->cand, (size_t)cap);
     e->d_cand_actions = dalloc<u8>(e, (size_t)cap * d.alen);
     e->d_cand_obs = dalloc<double>(e, (size_t)cap * d.obslen);
     e->d_cand_ids = dalloc<int>(e, (size_t)cap);
-    if (!e->d_cand_actions || !e->d_cand_obs || !e->d_cand_ids) return fail(e, PPN_E_HIP, "candidate slots: device allocation failed");
+    e->cand_allocs.assign(e->allocs.begin() + mark, e->allocs.end());      // (dalloc files everything under e->allocs)
+    e->allocs.resize(mark);
+    if (e->mem_failed) {
+      e->mem_failed = false;
+      for (void* p : e->cand_allocs) dev_free(p);
+      e->cand_allocs.clear();
+      return fail(e, PPN_E_HIP, "candidate slots: device allocation failed: %s", dev_err());
+    }
     e->cand_cap = cap;
   }
   e->n_cand = n;
@@ -956,7 +985,7 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
   GR(st, u8, d.nl) GR(rec, int, d.nl) GR(lcd, int, d.nl) GR(ncd, int, d.nS) GR(soft, int, d.nl)
   GR(done, u8, 1) GR(dead, u8, 1) GR(succ, u8, 1) GR(btype, u8, d.nrows) GR(flag, int, 1) GR(ill, int, 1)
   GR(depth, int, 1) GR(nsolve, int, 1) GR(niter, int, 1) GR(slot, int, 1) GR(row, int, 1) GR(nlc, int, 1)
-  GR(npc, int, 1) GR(epoch, int, 1)
+  GR(npc, int, 1) GR(epoch, int, 1) GR(prow, int, 1) GR(lev, u8, d.nl) GR(src, int, 1) GR(draws, unsigned, 1)
   GR(ws_tri, u64, d.TCAP) GR(ws_pair, u64, d.MCAP) GR(ws_piv, unsigned, d.NB) GR(ws_cache, u8, d.cache_stride)
 #undef GR
   if (rc) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err());

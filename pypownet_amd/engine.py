@@ -16,6 +16,8 @@ MODE_AC, MODE_DC = 0, 1
 SOLVER_NEWTON, SOLVER_FDXB = 1, 2
 FLAG_OK, FLAG_DIVERGED, FLAG_TOO_MANY_LOADS, FLAG_TOO_MANY_PRODS, FLAG_ENGINE_CAPACITY = 0, 1, 2, 3, 4
 ILL_TOO_MANY, ILL_BROKEN_LINE, ILL_LINE_COOLDOWN, ILL_NODE_COOLDOWN = 1, 2, 4, 8
+EV_SWITCHED, EV_MAINTENANCE, EV_HAZARD, EV_HARD_OVERFLOW, EV_SOFT_OVERFLOW = 1, 2, 4, 8, 16      # LINE_EVENTS bits
+SOLVE_CONVERGED, SOLVE_OUTAGE, SOLVE_NOT_CONNEXE, SOLVE_CAPACITY = 0, 1, 2, 4                      # SOLVE_OUTCOME
 
 
 class EngineError(RuntimeError):
@@ -23,7 +25,7 @@ class EngineError(RuntimeError):
 
 
 def rules_from_conf(conf, without_overflow_cutoff=False, game_over_mode='soft', looping_mode='natural',
-                    max_active_buses=0, lu_capacity=0):
+                    max_active_buses=0, lu_capacity=0, rng_seed=0):
     """Build the ppn_rules struct from a parsed configuration.yaml (pypownet/parameters.py keys)."""
     r = _lib.PpnRules()
     r.mode = MODE_DC if str(conf.get('loadflow_mode', 'AC')).lower() == 'dc' else MODE_AC
@@ -45,9 +47,10 @@ def rules_from_conf(conf, without_overflow_cutoff=False, game_over_mode='soft', 
     r.max_number_actionned_lines = int(conf['max_number_actionned_lines'])
     r.max_number_actionned_total = int(conf['max_number_actionned_total'])
     r.game_over_mode_hard = 1 if game_over_mode == 'hard' else 0
-    if looping_mode not in ('natural', 'fixed'):
-        raise ValueError('the batched engine supports chronic looping modes "natural" and "fixed"')
-    r.chronic_looping = 0 if looping_mode == 'natural' else 1
+    if looping_mode not in ('natural', 'fixed', 'random'):
+        raise ValueError('chronic looping mode should be "natural", "fixed" or "random"')
+    r.chronic_looping = {'natural': 0, 'fixed': 1, 'random': 2}[looping_mode]
+    r.rng_seed = int(rng_seed) & 0x7fffffff
     r.max_active_buses = int(max_active_buses)
     r.lu_capacity = int(lu_capacity)
     return r

@@ -279,9 +279,23 @@ class Observation(MinimalistACObservation):
             o += n
         return cls(**kw)
 
+    _INT_FIELDS = ('lines_status', 'are_loads_cut', 'are_productions_cut', 'substations_ids', 'loads_substations_ids',
+                   'productions_substations_ids', 'lines_or_substations_ids', 'lines_ex_substations_ids',
+                   'productions_nodes', 'loads_nodes', 'lines_or_nodes', 'lines_ex_nodes')
+    _DATE_FIELDS = ('date_year', 'date_month', 'date_day', 'date_hour', 'date_minute', 'date_second')
+
     @classmethod
-    def from_array(cls, case, array):
-        return cls._from_sizes(_field_sizes(case.nP, case.nL, case.nl, case.nS), np.asarray(array))
+    def from_array(cls, case, array, typed=False):
+        """typed=False: plain slices of the array, what the reference's ObservationSpace.array_to_observation builds
+        (environment.py:376-403).  typed=True: the types Game.export_observation hands out (grid.py:496-566,
+        game.py:945-978): integer ids / status / cut masks / node bits, Python ints for the date fields."""
+        o = cls._from_sizes(_field_sizes(case.nP, case.nL, case.nl, case.nS), np.asarray(array))
+        if typed:
+            for f in cls._INT_FIELDS:
+                setattr(o, f, np.asarray(getattr(o, f)).astype(int))
+            for f in cls._DATE_FIELDS:
+                setattr(o, f, int(np.asarray(getattr(o, f)).reshape(-1)[0]))
+        return o
 
     def as_dict(self):
         return self.__dict__

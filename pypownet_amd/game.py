@@ -13,7 +13,7 @@ import numpy as np
 from .case import Case
 from .chronic import Chronic, ChronicLooper, load_chronic
 from .engine import (Engine, FLAG_DIVERGED, FLAG_TOO_MANY_LOADS, FLAG_TOO_MANY_PRODS, FLAG_ENGINE_CAPACITY,
-                     ILL_TOO_MANY, ILL_BROKEN_LINE, ILL_LINE_COOLDOWN, ILL_NODE_COOLDOWN)
+                     ILL_TOO_MANY, ILL_BROKEN_LINE, ILL_LINE_COOLDOWN, ILL_NODE_COOLDOWN, SOLVE_NOT_CONNEXE)
 from .parameters import Parameters
 
 
@@ -202,18 +202,19 @@ class Game(object):
         self.game_over_mode = game_over_mode
 
         looper = ChronicLooper(p.get_chronics_path(), game_level, chronic_starting_id, chronic_looping_mode)
-        if chronic_looping_mode == 'random':
-            raise ValueError('chronic_looping_mode "random" is host-side only in the reference and is not supported '
-                             'by the device engine; use "natural" or "fixed"')
-        # the engine holds every chronic of the level; slot order = play order starting at chronic_starting_id
+        # the engine holds every chronic of the level; slot order = play order starting at the first chronic played.
+        # 'random' (chronic.py:266-291): the first chronic is drawn on the host like the reference does (np.random, so
+        # RunEnv(seed=...) controls it), the later ones on the device from a counter-based generator seeded from the same
+        # host stream (include/ppn.h, PPN_LOOP_RANDOM)
         n = len(looper.chronics)
-        order = [(chronic_starting_id + k) % n for k in range(n)] if chronic_looping_mode == 'natural' \
-            else [chronic_starting_id]
+        first = looper.next_chronic_id
+        order = [first] if chronic_looping_mode == 'fixed' else [(first + k) % n for k in range(n)]
         self._chronics = [load_chronic(looper.chronics[k]) for k in order]
         self.case = Case.from_file(p.get_reference_grid_path())
         self.engine = Engine(self.case, conf, 1, device=device, chronics=self._chronics,
                              without_overflow_cutoff=without_overflow_cutoff, game_over_mode=game_over_mode,
-                             looping_mode=chronic_looping_mode)
+                             looping_mode=chronic_looping_mode,
+                             rng_seed=int(np.random.randint(0, 2 ** 31 - 1)) if chronic_looping_mode == 'random' else 0)
         self.substations_ids = self.case.sub_ids.astype(float)
         self.grid = self            # agents reach game.grid.get_topology().mapping_array etc.
         self.number_elements_per_substations = list(self.case.n_elements)
@@ -258,7 +259,7 @@ class Game(object):
     # ---- observation ------------------------------------------------------------------------------------
     def export_observation(self, simulation=False):
         from .environment import Observation
-        return Observation.from_array(self.case, self.engine.observations(simulation=simulation)[0])
+        return Observation.from_array(self.case, self.engine.observations(simulation=simulation)[0], typed=True)
 
     # ---- actions ----------------------------------------------------------------------------------------
     def get_changed_substations(self, action):
@@ -298,27 +299,37 @@ class Game(object):
         if line_cd.any():
             text += 'Trying to action on-cooldown line%s %s, must wait resp. %s timesteps. ' % (
                 's' if line_cd.sum() > 1 else '', ', '.join(map(str, np.where(line_cd)[0])),
-                ', '.join(str(int(x)) for x in lcd[line_cd]))
+                ('resp. ' if line_cd.sum() > 1 else '') + ', '.join(str(int(x)) for x in lcd[line_cd]))     # (sic, game.py:717-723)
         if node_cd.any():
             text += 'Trying to action on-cooldown substation%s %s, must wait resp. %s timesteps.' % (
                 's' if node_cd.sum() > 1 else '', ', '.join(map(str, np.where(node_cd)[0])),
-                ', '.join(str(int(x)) for x in ncd[node_cd]))
+                ('resp. ' if node_cd.sum() > 1 else '') + ', '.join(str(int(x)) for x in ncd[node_cd]))
         e = IllegalActionException(text, False, broken if broken.any() else None, line_cd if line_cd.any() else None,
                                    node_cd if node_cd.any() else None)
+        # the repair of Game.step (game.py:816-846) edits the Action object in place and extends the text
         if broken.any():
             action.lines_status_subaction[broken] = 0
+            e.text += ' Ignoring action switches of broken/on-maintenance lines: %s.' % ', '.join(map(str, np.where(broken)[0]))
         if line_cd.any():
             action.lines_status_subaction[line_cd] = 0
+            e.text += ' Ignoring action switches of on-cooldown lines: %s.' % ', '.join(map(str, np.where(line_cd)[0]))
         if node_cd.any():
+            changed = self.substations_ids[node_cd]
             for sid in self.case.sub_ids[node_cd]:
                 n_el = len(action.get_substation_switches(sid, False)[1])
                 action.set_substation_switches(sid, np.zeros(n_el))
+            # (the reference prints np.where() of the id list itself, game.py:845-846)
+            e.text += ' Ignoring node switches of on-cooldown substations: %s.' % ', '.join(map(str, np.where(changed)[0]))
         return e
 
-    def _flag_object(self, flag):
+    def _flag_object(self, flag, sim=False):
         if flag == FLAG_DIVERGED:
-            return DivergingLoadflowException(None, 'Power grid outage: cascading emulation of depth %d has diverged'
-                                              % int(self.engine.read('CASCADE_DEPTH')[0]))
+            # grid.py:231, 238 ('The grid is not connexe': the solver raised) vs grid.py:264 ('Power grid outage': no
+            # convergence or NaN), extended by the cascade (game.py:515)
+            outcome = int(self.engine.read('SOLVE_OUTCOME', simulation=sim)[0])
+            return DivergingLoadflowException(None, '%s: cascading emulation of depth %d has diverged' % (
+                'The grid is not connexe' if outcome == SOLVE_NOT_CONNEXE else 'Power grid outage',
+                int(self.engine.read('CASCADE_DEPTH', simulation=sim)[0])))
         if flag == FLAG_TOO_MANY_LOADS:
             return TooManyConsumptionsCut('There are %d isolated loads; at most %d tolerated' % (
                 int(self.engine.read('N_LOADS_CUT')[0]), self.max_number_loads_game_over))
@@ -345,8 +356,10 @@ class Game(object):
             eng.step(a)
         sim = bool(_is_simulation)
         done = bool(eng.read('DONE', simulation=sim)[0])
-        flag = self._flag_object(int(eng.read('FLAG', simulation=sim)[0]))
+        flag = self._flag_object(int(eng.read('FLAG', simulation=sim)[0]), sim)
         bits = int(eng.read('ILLEGAL', simulation=sim)[0])
+        if bits:
+            self.timestep += 1       # the repaired action is re-submitted: apply_action runs a second time (game.py:600, 849)
         illegal = self._illegal_exception(action, bits, counters) if bits else None
         if flag is None:
             flag = illegal

@@ -8,9 +8,12 @@ Same folder layout and the same 17 mandatory scalar keys.  Differences, all addi
   * the grid may be ``reference_grid.py`` (PYPOWER case format) or ``reference_grid.json``;
   * ``overrides`` lets a caller change keys without touching a read-only folder.
 """
+import contextlib
 import importlib.util
 import logging
 import os
+import sys
+import types
 
 import yaml
 
@@ -24,6 +27,34 @@ _MANDATORY_KEYS = [
     'n_timesteps_actionned_node_reactionable', 'n_timesteps_pending_line_reactionable_when_overflowed',
     'n_timesteps_pending_node_reactionable_when_overflowed', 'max_number_actionned_substations',
     'max_number_actionned_lines', 'max_number_actionned_total']
+
+
+@contextlib.contextmanager
+def _reference_package_aliases():
+    """An environment folder's ``reward_signal.py`` is written against the reference package: it imports
+    ``pypownet.environment`` / ``pypownet.reward_signal`` and tests the step flag with ``isinstance(flag,
+    pypownet.environment.DivergingLoadflowException)`` (parameters/default14/reward_signal.py:1-3, 48-60).  While such
+    a file is executed, the names ``pypownet`` and ``pypownet.<module>`` resolve to this package's modules, so that the
+    unmodified file loads here and its isinstance checks see the exception classes RunEnv.step actually returns -- also
+    when the reference package itself happens to be installed."""
+    from . import environment, reward_signal, game, chronic
+    pkg = types.ModuleType('pypownet')
+    pkg.__path__ = []
+    mods = {'pypownet': pkg, 'pypownet.environment': environment, 'pypownet.reward_signal': reward_signal,
+            'pypownet.game': game, 'pypownet.chronic': chronic, 'pypownet.parameters': sys.modules[__name__]}
+    for k, m in mods.items():
+        if k != 'pypownet':
+            setattr(pkg, k.split('.', 1)[1], m)
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        yield
+    finally:
+        for k, m in saved.items():
+            if m is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = m
 
 
 class Parameters(object):
@@ -64,11 +95,12 @@ class Parameters(object):
         self.reward_signal_class = RewardSignal
         if os.path.exists(reward_path):
             try:
-                spec = importlib.util.spec_from_file_location('reward_signal_%d' % abs(hash(reward_path)), reward_path)
-                mod = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(mod)
+                with _reference_package_aliases():
+                    spec = importlib.util.spec_from_file_location('reward_signal_%d' % abs(hash(reward_path)), reward_path)
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
                 self.reward_signal_class = getattr(mod, 'CustomRewardSignal')
-            except Exception as e:  # same fallback as the reference on ImportError
+            except Exception as e:  # same fallback as the reference on ImportError (parameters.py:55-70)
                 self.logger.error('/!\\ Using default reward signal (%s)' % e)
 
     def get_reward_signal_class(self): return self.reward_signal_class

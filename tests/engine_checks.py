@@ -6,6 +6,7 @@ import numpy as np
 from helpers import (load_env, oracle_game, do_nothing, set_line_switch, set_substation_switches,
                      nodes_of_substation, differential)
 from oracle.game_np import obs_as_array
+from oracle import obs_np
 from harness import engine_with_library, ORACLE_LIB
 
 TOL_V = 1e-6      # p.u. / rad: the parity bar of BASELINE.json's north_star
@@ -17,7 +18,7 @@ def make_engine(lib_path, envname, batch, conf=None, **kw):
     return engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw), case, cfg, chronics
 
 
-def compare_state(eng, games, tol_v=1e-8):
+def compare_state(eng, games, tol_v=1e-8, chronic_position=False):
     vm, va = eng.read('VM'), eng.read('VA')
     pg, qg = eng.read('PG'), eng.read('QG')
     pf, qf, pt, qt = eng.read('PF'), eng.read('QF'), eng.read('PT'), eng.read('QT')
@@ -44,9 +45,16 @@ def compare_state(eng, games, tol_v=1e-8):
         assert np.array_equal(lcd[b], g.line_cooldown.astype(int))
         assert np.array_equal(ncd[b], g.node_cooldown.astype(int))
         assert np.array_equal(soft[b], g.n_soft_overflowed.astype(int))
+    if chronic_position:      # which chronic the environment plays and where it stands in it (roll-over q2, hard game over)
+        slot, row = eng.read('CHRONIC_SLOT'), eng.read('CHRONIC_ROW')
+        for b, g in enumerate(games):
+            if g is None:
+                continue
+            assert int(slot[b]) == g.current_chronic_slot, 'chronic of env %d: %d vs %d' % (b, slot[b], g.current_chronic_slot)
+            assert g.chronic.get_timestep_ids()[int(row[b])] == g.current_timestep_id, 'timestep id of env %d' % b
 
 
-def lockstep(eng, games, actions_per_step, tol_v=1e-8, check_obs=False):
+def lockstep(eng, games, actions_per_step, tol_v=1e-8, check_obs=False, chronic_position=False):
     """Steps engine and oracles with the same actions (WrappedRunner protocol: a done env is passed through
     process_game_over) and compares flags and full state after every step."""
     case = games[0].case
@@ -61,7 +69,7 @@ def lockstep(eng, games, actions_per_step, tol_v=1e-8, check_obs=False):
             assert int(flag[b]) == f, 'flag differs at step %d env %d: %d vs %d' % (t, b, flag[b], f)
             assert int(ill[b]) == i, 'illegal bits differ at step %d env %d' % (t, b)
         alive = [None if exp[b][3] else g for b, g in enumerate(games)]
-        compare_state(eng, alive, tol_v)
+        compare_state(eng, alive, tol_v, chronic_position)
         if check_obs:
             obs = eng.observations()
             for b, g in enumerate(alive):
@@ -72,7 +80,7 @@ def lockstep(eng, games, actions_per_step, tol_v=1e-8, check_obs=False):
             for b, g in enumerate(games):
                 if exp[b][3]:
                     g.process_game_over()
-            compare_state(eng, games, tol_v)
+            compare_state(eng, games, tol_v, chronic_position)
 
 
 def check_do_nothing(lib_path, env, solver, steps=12, batch=2):
@@ -143,6 +151,7 @@ def _force_game_over(eng):
 
 
 def check_topology_scenarios(lib_path, env, nodes, n_iter, policy_factory, solver='fdxb', conf=None):
+    check_obs = not (lib_path and 'liboracle' in lib_path)
     cf = {'solver': solver}
     if conf:
         cf.update(conf)
@@ -173,6 +182,11 @@ def check_topology_scenarios(lib_path, env, nodes, n_iter, policy_factory, solve
         if done.any():
             eng.process_game_over()
         compare_state(eng, games)
+        if check_obs:      # Observation.as_array() gathered on the device, with split nodes (are_*_cut, voltages of moved elements, q9)
+            got = eng.observations()
+            for b, g in enumerate(games):
+                np.testing.assert_allclose(got[b], obs_as_array(g.export_observation()), rtol=0, atol=TOL_FLOW,
+                                           err_msg='observation of env %d at step %d' % (b, i))
     return flags_seen
 
 
@@ -233,7 +247,7 @@ def random_actions(case, rng, batch, p_node=0.6, p_line=0.3):
 
 
 def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='newton', seed=1234, conf=None,
-                                      max_dropped=None, excuse_vm=0.0, **engine_kw):
+                                      max_dropped=None, excuse_vm=0.0, check_obs=True, obs_every=3, obs_envs=24, **engine_kw):
     """Lock-step with the C oracle under random node-splitting / line-switching actions (dynamic Ybus rebuild every
     step, illegal-action repair, cooldowns, islanding, game overs + auto reset): flags, topology, counters bit-exact,
     voltages <= 1e-8 on live environments."""
@@ -246,7 +260,7 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
     case, cfg, chronics = load_env(envname, conf=cf)
     case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
     eng = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)
-    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics)
+    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics, **engine_kw)
     rng = np.random.default_rng(seed)
     eng.reset()
     orc.reset()
@@ -285,7 +299,7 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
             bad |= df
         for f in ('DONE', 'FLAG', 'ILLEGAL', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES',
                   'LINES_EX_NODES', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN', 'SOFT_COUNT', 'CHRONIC_ROW',
-                  'CHRONIC_SLOT', 'N_LOADS_CUT', 'N_PRODS_CUT', 'CASCADE_DEPTH'):
+                  'CHRONIC_SLOT', 'N_LOADS_CUT', 'N_PRODS_CUT', 'CASCADE_DEPTH', 'LINE_EVENTS', 'SOLVE_OUTCOME'):
             note(f, (eng.read(f) != orc.read(f)).reshape(batch, -1).any(axis=1))
         ns_e, ns_o = eng.read('N_SOLVES').astype(np.int64), orc.read('N_SOLVES').astype(np.int64)
         note('N_SOLVES', (ns_e - prev_ns[0]) != (ns_o - prev_ns[1]))      # solves of THIS step
@@ -302,6 +316,19 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
             note(name, d.any(axis=1))
         assert not (bad & tracked & ~excusable).any(), '%s differs at step %d (envs %s)' % (
             first_bad, t, np.where(bad & tracked & ~excusable)[0][:8])
+        if check_obs and t % obs_every == 0:
+            # Observation.as_array() and the reduced layouts gathered on the device against arrays rebuilt from the C ORACLE's
+            # state by oracle/obs_np.py (the state after the fused restart for environments that just ended)
+            ost = obs_np.read_state(orc)
+            got = {lay: eng.observations(layout=lay) for lay in ('full', 'minimalist', 'ac_minimalist')}
+            got32 = eng.observations(layout='minimalist', dtype=np.float32)
+            for b in np.where(tracked & ~bad & ~(min_vm < 1e-6))[0][:obs_envs]:
+                od = obs_np.observation_dict(case, cfg, chronics, orc.thermal_limits, ost, b)
+                for lay in got:
+                    np.testing.assert_allclose(got[lay][b], obs_np.reduced_array(od, lay), rtol=0, atol=TOL_FLOW, equal_nan=True,
+                                               err_msg='%s observation of env %d at step %d' % (lay, b, t))
+                assert np.array_equal(got32[b], got['minimalist'][b].astype(np.float32), equal_nan=True)
+            stats['obs_checked'] = stats.get('obs_checked', 0) + 1
         stats['excused'] += int((bad & tracked).sum())
         # an environment that was dropped is compared again once its whole state (topology, counters, chronic position, warm
         # start) agrees again -- normally right after the restart that follows its game over
@@ -386,6 +413,7 @@ def check_candidate_search(lib_path, envname, batch, n_actions, warm_steps=4, se
         eng.step(act0, auto_reset=True)
         orc.step(act0, auto_reset=True)
     before = {f: eng.read(f).copy() for f in ('VM', 'VA', 'LINES_STATUS', 'LINES_OR_NODES', 'RECONNECTABLE', 'CHRONIC_ROW', 'N_SOLVES')}
+    live_pos = (orc.read('CHRONIC_SLOT').copy(), orc.read('CHRONIC_ROW').copy())
     cands = [random_actions(case, rng, batch, p_node=0.8, p_line=0.5) for _ in range(n_actions)]
     cands[0][:] = 0                                                   # candidate 0: do nothing
     acts = np.stack(cands, axis=1).reshape(batch * n_actions, -1)     # candidate c = env * n_actions + k
@@ -413,9 +441,147 @@ def check_candidate_search(lib_path, envname, batch, n_actions, warm_steps=4, se
         np.testing.assert_allclose(got['VM'][sel][lv], vm_o[lv], rtol=0, atol=1e-8)
         eng.simulate(cands[k])        # the engine's own one-action-per-environment simulate: same observation rows
         assert np.array_equal(obs[sel][live], eng.observations(simulation=True)[live], equal_nan=True)
+        # ... and the simulated observation itself against the array rebuilt from the ORACLE's simulated state: planned_* series
+        # of the entry the simulation started from (quirk q11), date / maintenance of the simulated timestep
+        sim_state = obs_np.read_state(orc, simulation=True)
+        for b in np.where(good)[0][:12]:
+            ref = obs_np.observation_array(case, cfg, chronics, orc.thermal_limits, sim_state, b,
+                                           planned_from=(live_pos[0][b], live_pos[1][b]))
+            np.testing.assert_allclose(obs[sel][b], ref, rtol=0, atol=TOL_FLOW, err_msg='simulated observation, action %d env %d' % (k, b))
         n_checked += int(good.sum())
     for f, v in before.items():
         assert np.array_equal(eng.read(f), v), 'candidate search changed the live %s' % f
     assert n_checked > batch      # plenty of successful candidates were compared
     return n_checked
 
+
+
+def check_hard_game_over_mode(lib_path, envname='default14', solver='newton', steps=45, batch=4, seed=5):
+    """RunEnv(game_over_mode='hard') (reference pypownet/game.py:762-780): a game over does not go on with the
+    next timestep of the chronic that failed but starts the NEXT chronic, at its SECOND timestep id (get_next_chronic sets
+    the current id to 0, then the id after it is loaded).  Lock-step against the numpy restatement under random node
+    splitting / line switching, several chronics, chronic position compared after every step and every restart."""
+    cf = {'solver': solver}
+    eng, case, cfg, chronics = make_engine(lib_path, envname, batch, conf=cf, game_over_mode='hard')
+    assert len(chronics) >= 2
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    games = [oracle_game(envname, conf=cf, game_over_mode='hard') for _ in range(batch)]
+    eng.reset()
+    compare_state(eng, games, chronic_position=True)
+    rng = np.random.default_rng(seed)
+    n_done, slots = 0, set()
+    for t in range(steps):
+        acts = random_actions(case, rng, batch, p_node=0.9, p_line=0.6)
+        before = eng.read('CHRONIC_SLOT').copy()
+        lockstep(eng, games, [acts], check_obs=not (lib_path and 'liboracle' in lib_path), chronic_position=True)
+        after, row = eng.read('CHRONIC_SLOT'), eng.read('CHRONIC_ROW')
+        moved = after != before
+        n_done += int(moved.sum())
+        # the quirk itself: every environment that changed chronic because of a game over stands on id index 1
+        for b in np.where(moved)[0]:
+            assert int(row[b]) == 1, 'hard restart resumed at row %d' % row[b]
+        slots.update(int(s) for s in after)
+    assert n_done >= 2 and len(slots) >= 2, (n_done, slots)
+    return n_done
+
+
+def check_random_chronic_looping(lib_path, envname='default14', steps=30, batch=48, seed=11):
+    """chronic_looping_mode='random' (reference pypownet/chronic.py:266-291): the next chronic is drawn uniformly at every
+    hard game over and at every roll-over.  The device draws from the counter-based generator include/ppn.h specifies;
+    lock-step with the C oracle's restatement of the same generator (hard mode, so that draws are frequent), both slots
+    must come up, and the draws must be reproducible under the seed and different under another one."""
+    cf = {'solver': 'newton'}
+    st = check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, 'newton', seed=seed, conf=cf, max_dropped=batch,
+                                          game_over_mode='hard', looping_mode='random', rng_seed=20260928)
+    assert st['done'] > batch // 4, st
+    seqs = []
+    for rng_seed in (20260928, 20260928, 7):
+        eng, case, cfg, chronics = make_engine(lib_path, envname, batch, conf=cf, game_over_mode='hard', looping_mode='random',
+                                               rng_seed=rng_seed)
+        eng.reset()
+        seen = []
+        for t in range(6):
+            eng.force_game_over()
+            seen.append(eng.read('CHRONIC_SLOT').copy())
+        seqs.append(np.stack(seen))
+    assert np.array_equal(seqs[0], seqs[1]) and not np.array_equal(seqs[0], seqs[2])
+    counts = np.bincount(seqs[0].ravel(), minlength=len(chronics))
+    assert (counts > 0.25 * seqs[0].size / len(chronics)).all(), counts       # every chronic comes up
+    return st
+
+
+def check_reduced_observation_layouts(lib_path, envname='default118', steps=4, batch=3):
+    """ppn_read_observation(layout): MinimalistObservation.as_array() / MinimalistACObservation.as_array() /
+    Observation.as_array() (reference environment.py:451-466, 511-517, 583-595) gathered on the device at their own row
+    stride, against the arrays the numpy oracle builds field by field; float32 = the rounded float64."""
+    cf = {'solver': 'newton'}
+    eng, case, cfg, chronics = make_engine(lib_path, envname, batch, conf=cf)
+    games = [oracle_game(envname, conf=cf) for _ in range(batch)]
+    eng.reset()
+    act = np.zeros((batch, case.action_length), dtype=np.uint8)
+    lengths = {}
+    for t in range(steps):
+        if t == 2:
+            act[0, case.nP + case.nL + 5] = 1          # one split line end: node bits / voltages of moved elements
+        eng.step(act)
+        exp = [g.step(act[b].astype(np.int64)) for b, g in enumerate(games)]
+        for lay in ('minimalist', 'ac_minimalist', 'full'):
+            got = eng.observations(layout=lay)
+            got32 = eng.observations(layout=lay, dtype=np.float32)
+            lengths[lay] = got.shape[1]
+            for b in range(batch):
+                assert not exp[b][3]
+                ref = obs_np.reduced_array(exp[b][0], lay)
+                assert got.shape[1] == len(ref)
+                np.testing.assert_allclose(got[b], ref, rtol=0, atol=TOL_FLOW)
+                np.testing.assert_allclose(got32[b], ref.astype(np.float32), rtol=1e-6, atol=1e-3)
+                assert np.array_equal(got32[b], got[b].astype(np.float32), equal_nan=True)
+        act[:] = 0
+    assert lengths['minimalist'] < lengths['ac_minimalist'] < lengths['full']
+    return lengths
+
+
+def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='newton', bench_limits=False, max_active_buses=None,
+                             game_over_mode='soft'):
+    """Lock-step with the C oracle at BASELINE.json's full batch sizes (configs[1]: default14 Newton x 1024 environments,
+    configs[2]: default118 Newton x 4096 environments with the cascade limits): do-nothing agent, environment e plays
+    chronic (e mod n) from row (37 e) mod T, auto game-over reset.  Flags, line status, counters, chronic
+    positions, cumulative solve and Newton-iteration counts bit-exact; voltages <= 1e-8 p.u. / rad on live buses."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env(envname, conf={'solver': solver})
+    kw = {}
+    if bench_limits:
+        with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
+            kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
+    ekw = dict(kw, game_over_mode=game_over_mode)
+    if max_active_buses:
+        ekw['max_active_buses'] = max_active_buses
+    eng = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **ekw)
+    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics, game_over_mode=game_over_mode, **kw)
+    slots, t0 = default_assignment(np.arange(batch), chronics)
+    eng.reset(chronic_slot=slots, t0=t0)
+    orc.reset(chronic_slot=slots, t0=t0)
+    act = np.zeros((batch, case.action_length), dtype=np.uint8)
+    worst, n_done = 0.0, 0
+    for t in range(steps):
+        eng.step(act, auto_reset=True)
+        orc.step(act, auto_reset=True)
+        n_done += int(orc.read('DONE').sum())
+        if (t + 1) % every and t + 1 != steps:
+            continue
+        for f in ('DONE', 'FLAG', 'LINES_STATUS', 'RECONNECTABLE', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES',
+                  'N_ITERS', 'CASCADE_DEPTH', 'N_LOADS_CUT', 'N_PRODS_CUT', 'LINE_EVENTS', 'SOLVE_OUTCOME'):
+            a, b = eng.read(f), orc.read(f)
+            assert np.array_equal(a, b), 'step %d: %s differs for environments %s' % (
+                t, f, np.where((a != b).reshape(batch, -1).any(axis=1))[0][:10])
+        live = orc.read('BUS_TYPE') != 4
+        dv = np.abs(eng.read('VM')[live] - orc.read('VM')[live]).max()
+        da = np.abs(np.deg2rad(eng.read('VA')[live]) - np.deg2rad(orc.read('VA')[live])).max()
+        worst = max(worst, dv, da)
+        assert dv <= 1e-8 and da <= 1e-8, (t, dv, da)
+        np.testing.assert_allclose(eng.read('AMPS'), orc.read('AMPS'), rtol=0, atol=1e-5)
+    return dict(solves=int(orc.read('N_SOLVES').astype(np.int64).sum()), done=n_done, worst=worst,
+                slots=len(set(int(s) for s in orc.read('CHRONIC_SLOT'))))

@@ -101,3 +101,26 @@ def test_emu_candidate_search_equals_simulate(emu_lib, env, batch, k):
 def test_emu_intermediate_busbar_capacity(emu_lib):
     st = ec.check_random_actions_vs_c_oracle(emu_lib, 'default118', 8, 4, 'newton', seed=77, max_active_buses=150)
     assert st['split_buses'] > 0
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_emu_hard_game_over_mode(emu_lib, solver):
+    assert ec.check_hard_game_over_mode(emu_lib, solver=solver) >= 2
+
+
+def test_emu_random_chronic_looping(emu_lib):
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
+    ec.check_random_chronic_looping(emu_lib)
+
+
+def test_emu_reduced_observation_layouts(emu_lib):
+    ec.check_reduced_observation_layouts(emu_lib, 'default14_for_tests', steps=6, batch=2)
+
+
+def test_emu_full_size_check_at_small_size(emu_lib):
+    """The full-size lock-step harness of the GPU tests (BASELINE.json configs[1] / configs[2]) on a few environments."""
+    st = ec.check_full_size_lockstep(emu_lib, 'default14', 16, 30, 10)
+    assert st['slots'] >= 2
+    st = ec.check_full_size_lockstep(emu_lib, 'default118', 6, 12, 4, bench_limits=True, max_active_buses=118, game_over_mode='hard')
+    assert st['done'] > 0

@@ -69,6 +69,36 @@ def test_gpu_random_actions_vs_c_oracle(env, solver, steps, batch):
 
 
 
+def test_gpu_full_size_default118_4096_bench_workload():
+    """BASELINE.json configs[2] at its full batch: 4096 environments of default118 (Newton, cascade limits, auto reset), 60 steps
+    of lock-step with the C oracle (about 0.3 M solves; tests/tools/soak_parity.py runs the long version)."""
+    st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 60, 20, bench_limits=True, max_active_buses=118)
+    assert st['done'] > 4096 and st['solves'] > 4096 * 60
+
+
+def test_gpu_full_size_default14_1024_newton():
+    """BASELINE.json configs[1]: default14 (its own chronics: every chronic the fixture carries, start row (37 e) mod T),
+    AC Newton-Raphson, 1024 environments, 200 steps against the C oracle."""
+    st = ec.check_full_size_lockstep(HIP, 'default14', 1024, 200, 40)
+    assert st['slots'] >= 2 and st['solves'] >= 1024 * 200
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_hard_game_over_mode(solver):
+    """game_over_mode='hard' against the numpy restatement (default14, random actions, chronic position after every restart)."""
+    assert ec.check_hard_game_over_mode(HIP, solver=solver, steps=60, batch=8) >= 2
+
+
+def test_gpu_hard_game_over_mode_118_auto_reset():
+    """... and against the C oracle on default118 with the fused restart (auto_reset), bench limits, 512 environments."""
+    st = ec.check_full_size_lockstep(HIP, 'default118', 512, 40, 10, bench_limits=True, max_active_buses=118, game_over_mode='hard')
+    assert st['done'] > 100 and st['slots'] >= 2
+
+
+def test_gpu_random_chronic_looping():
+    ec.check_random_chronic_looping(HIP, batch=96, steps=40)
+
+
 def test_gpu_config1_default14_dc_1000_steps():
     """BASELINE.json configs[0] through the HIP engine: default14 in DC mode, do-nothing, 1000 timesteps across the end of
     the first chronic, against the numpy restatement step by step."""
@@ -113,21 +143,9 @@ def test_gpu_candidate_search_equals_simulate(env, batch, k):
 
 
 def test_gpu_reduced_observation_layouts():
-    """Reduced / float32 observation layouts gathered on the GPU are prefixes (resp. roundings) of Observation.as_array()."""
-    import os
-    from helpers import load_env
-    from pypownet_amd.engine import Engine
-    case, cfg, chronics = load_env('default118', conf={'solver': 'newton'})
-    eng = Engine(case, cfg, 8, chronics=chronics)
-    eng.reset()
-    eng.step(np.zeros((8, case.action_length), dtype=np.uint8))
-    full = eng.observations()
-    for lay in ('minimalist', 'ac_minimalist', 'full'):
-        o = eng.observations(layout=lay)
-        assert np.array_equal(o, full[:, :o.shape[1]], equal_nan=True)
-        o32 = eng.observations(layout=lay, dtype=np.float32)
-        assert np.array_equal(o32, o.astype(np.float32), equal_nan=True)
-    assert eng.observations(layout='minimalist').shape[1] < full.shape[1] // 2
+    """Reduced / float32 observation layouts gathered on the GPU against the numpy oracle's field-by-field arrays."""
+    ec.check_reduced_observation_layouts(HIP, 'default118')
+    ec.check_reduced_observation_layouts(HIP, 'default14_for_tests', steps=6, batch=2)
 
 
 @pytest.mark.parametrize('cap,solver', [(150, 'newton'), (128, 'newton'), (150, 'fdxb')])
