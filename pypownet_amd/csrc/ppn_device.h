@@ -36,7 +36,11 @@ static inline int ppn_popc(u64 x) { return __builtin_popcountll(x); }
 static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #else
 #define PPN_DEV __device__ __forceinline__
-#define LANE_LOOP for (int lane = lane0, once_ = 1; once_; once_ = 0)
+// (every phase takes an OPAQUE copy of the lane index: address arithmetic and trip counts that depend only on the lane are
+//  loop invariants of the episode / cascade / Newton loops, and hoisted out of them they would sit in VGPRs for the whole
+//  kernel -- hundreds of them; recomputing them per phase costs a few VALU instructions)
+__device__ __forceinline__ int ppn_opaque_lane(int x) { __asm__ volatile("" : "+v"(x)); return x; }
+#define LANE_LOOP for (int lane = ppn_opaque_lane(lane0), once_ = 1; once_; once_ = 0)
 // One wavefront per workgroup: the LDS unit executes the DS instructions of a wave in issue order (a ds_read issued
 // after a ds_write / ds_add of any lane of the same wave observes it), so ordering LDS phases only needs the COMPILER
 // not to move memory accesses across the point; the waits for loaded registers are the compiler's own.  Nothing is
@@ -111,7 +115,8 @@ struct DevRules {
 // Static (shared by all environments) + chronic tensors.  All pointers are device pointers.
 struct DevCase {
   int nS, nP, nL, nl, nrows, ntopo, alen, obslen;
-  int NB, YCAP, LUCAP, ECAP;   // capacities: active buses, Ybus entries, LU doubles (= 4*ECAP), filled pattern entries
+  int NB, YCAP, LUCAP, ECAP;   // capacities: active buses, Ybus entries, LU doubles (Newton: 2 (ECAP + QCAP)), filled pattern entries
+  int QCAP;                    // capacity of the Q plane of the Newton storage: pattern entries in rows of PQ buses (<= ECAP)
   double baseMVA;
   const double *bus_gs, *bus_bs, *bus_kv, *vm0, *va0;   // [nrows]  (va0 degrees)
   const int *gen_sub, *load_sub, *or_sub, *ex_sub;       // substation index of each element
@@ -127,7 +132,7 @@ struct DevCase {
   int nlev;
   int MCAP, TCAP;        // schedule capacities: pivot-neighbour pairs, update triples
   // per-environment schedule cache (global memory): byte offsets of its tables inside one environment's blob
-  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, co_fill, cache_stride;
+  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_rowptr, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, co_fill, cache_stride;
   // the schedule of the reference topology (every element on busbar 0), shared by all environments: one copy of the
   // tables and records that stays in the L2s instead of `batch` private ones streaming from HBM.  Null until the first
   // ppn_reset has produced it.
@@ -173,22 +178,38 @@ struct DevState {
   u8 *ws_cache;                    // [cache_stride] schedule cache: header, node-assignment signature, index tables
 };
 
-// LDS carve-up (pointers into the workgroup's dynamic shared memory).  The arrays of the "setup" group are only
-// alive while a solve is being prepared (pattern, schedule) or outside a solve (action decoding, ampere flows) and
-// are overlaid on the matrix storage `lu`, which is dead at those times.
+// LDS carve-up (pointers into the workgroup's dynamic shared memory).
+//   * arrays that live across a whole step (topology working copies, cascade flags, ampere flows),
+//   * arrays that live across one solve (bus maps, types, the vectors the Newton loop accesses at random),
+//   * ONE region R that is, in turn: the scratch of schedule_build; the setup scratch of a solve (adjacency bitsets,
+//     temporary Ybus, production flags) next to the solve's bus vectors (vm, va, injections, mismatch); the matrix storage.
+//     The Newton kernels keep the bus vectors in registers while their matrix storage -- which overlays them -- is alive,
+//     the fast-decoupled / DC kernels have them next to their (smaller) factors.
+// Newton matrix storage = two planes of 16-byte half blocks on the filled pattern: the P plane holds, for EVERY pattern entry
+// (i,j), the row of the P_i equation (dP_i/dVa_j, dP_i/dVm_j); the Q plane holds the row of the Q_i equation only for buses
+// that have one (PQ buses: nv == 2).  A PV bus or the reference bus has no Q row, so its entries take no Q storage: qrel[i] is
+// the byte offset that turns entry index e of a row-i entry into its Q half ((char*)lu + qrel[i] + 16 e), 0xFFFF = no Q row.
 struct Smem {
-  // persistent during a solve
-  double *lu;
-  double *vm, *va, *vc, *ivm, *psp, *qsp, *mr, *mi, *rhs;   // vc: V = vc[2i] + j vc[2i+1]; ivm: 1 / |V_i|
-  u16 *int2row, *lvlp, *lvlm, *lvlt, *ediag;
-  u8 *row2int, *r2s, *nv, *st, *on, *en, *pn, *ln, *lf, *lt;   // r2s: bus row -> schedule index (superset), row2int: live buses only
-  // setup group (aliases lu)
-  u64 *adj0, *adjF;
-  double *yre, *yim, *gvg, *amps;
-  u16 *yptr, *scn, *moffq, *toffq, *rowptr;
-  unsigned *ymeta;
-  u8 *pvl, *kq, *mem, *mown, *subchg, *act, *touched, *hasgen, *genon, *over;
+  // across the step
+  u8 *st, *on, *en, *pn, *ln, *over, *subchg, *touched;
+  double* amps;
+  // across a solve
+  u8 *row2int, *r2s, *nv, *lf, *lt;   // r2s: bus row -> schedule index (superset), row2int: live buses only
+  u16 *int2row, *ediag, *qrel;
+  double *vc, *ivm, *rhs, *zero;      // vc: V = vc[2i] + j vc[2i+1]; ivm: 1 / |V_i|; zero: {0, 0, 0, 1} = the halves a missing Q row reads as
+  // region R
+  double* lu;
+  double *vm, *va, *psp, *qsp, *mr, *mi;      // bus vectors (view of R)
+  u64 *adj0;                                   // setup scratch of a solve (view of R)
+  double *yre, *yim, *gvg;
+  u8 *hasgen, *genon;
+  u64* adjF;                                   // schedule_build scratch (view of R, with adj0)
+  u16 *yptr, *scn, *moffq, *toffq, *rowptr, *lvlp, *lvlm, *lvlt;
+  u8 *pvl, *kq, *mem, *mown;
+  // compact carve only (is_action_valid)
+  u8* act;
 };
+#define PPN_QNONE 0xFFFFu
 
 #ifdef PPN_EMU
 #define PPN_HD static inline
@@ -204,10 +225,10 @@ PPN_HD unsigned ppn_mix32(unsigned seed, unsigned env, unsigned draw) {
 }
 
 // Single definition of the LDS layout: carves `base` into S and returns the total size in bytes
-// (call with base == nullptr on the host to size the launch).
+// (call with base == nullptr on the host to size the launch).  NT: solver flavour of the kernel (1: Newton).
 // compact = true: only what the kernels without a solve touch (observation gather, is_action_valid) -- a few KB instead of
 // the solver's working set, so that all their workgroups are resident at once.
-PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp, bool compact = false) {
+PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Smem* Sp, bool compact = false) {
   Smem& S = *Sp;
   size_t o = 0;
   const size_t NB = d.NB, nl = d.nl, nrows = d.nrows;
@@ -217,30 +238,35 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, unsigned char* base, Smem* Sp, 
     PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
     return o;
   }
-  // setup group first (overlaid on lu)
-  PPN_TAKE(adj0, u64, NB * W * 8) PPN_TAKE(adjF, u64, NB * W * 8)
-  PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8)
-  PPN_TAKE(amps, double, nl * 8) PPN_TAKE(ymeta, unsigned, (size_t)d.YCAP * 4)
-  PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(scn, u16, (nrows + 1) * 2)
-  PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)
-  PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
-  PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(touched, u8, nrows) PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
-  PPN_TAKE(over, u8, nl)
-  PPN_TAKE(gvg, double, NB * 8) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
-  const size_t setup_bytes = o;
-  const size_t lu_bytes = (size_t)d.LUCAP * 8;
-  S.lu = (double*)base;
-  o = (setup_bytes > lu_bytes ? setup_bytes : lu_bytes);
-  o = (o + 15) & ~(size_t)15;
-  PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(ivm, double, NB * 8)
-  PPN_TAKE(psp, double, NB * 8) PPN_TAKE(qsp, double, NB * 8)
-  PPN_TAKE(mr, double, NB * 8) PPN_TAKE(mi, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8)
-  PPN_TAKE(int2row, u16, NB * 2)
-  PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
-  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(ediag, u16, NB * 2)
-  PPN_TAKE(row2int, u8, nrows) PPN_TAKE(r2s, u8, nrows) PPN_TAKE(nv, u8, NB)
   PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
-  PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl)
+  PPN_TAKE(over, u8, nl) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(touched, u8, nrows) PPN_TAKE(amps, double, nl * 8)
+  PPN_TAKE(row2int, u8, nrows) PPN_TAKE(r2s, u8, nrows) PPN_TAKE(nv, u8, NB) PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl)
+  PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(ediag, u16, NB * 2) PPN_TAKE(qrel, u16, NB * 2)
+  PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(ivm, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
+  const size_t r0 = o;
+  S.lu = (double*)(base + r0);
+  // view: schedule_build scratch
+  PPN_TAKE(adj0, u64, NB * W * 8)
+  const size_t after_adj0 = o;
+  PPN_TAKE(adjF, u64, NB * W * 8)
+  PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(scn, u16, (nrows + 1) * 2) PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)
+  PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
+  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2)
+  PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
+  const size_t build_end = o;
+  // view: setup scratch of a solve (adj0 shared with the view above), then the bus vectors
+  o = after_adj0;
+  PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8) PPN_TAKE(gvg, double, NB * 8)
+  PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
+  const size_t fd_lu_end = r0 + (size_t)d.ECAP * 16;      // B' and B'' as scalar matrices: 2 x ECAP doubles
+  if (!NT && o < fd_lu_end) o = fd_lu_end;               // (fast-decoupled / DC: the vectors sit beside the factors)
+  PPN_TAKE(vm, double, NB * 8) PPN_TAKE(va, double, NB * 8) PPN_TAKE(psp, double, NB * 8) PPN_TAKE(qsp, double, NB * 8)
+  PPN_TAKE(mr, double, NB * 8) PPN_TAKE(mi, double, NB * 8)
+  const size_t vec_end = o;
+  const size_t lu_end = NT ? r0 + ((size_t)d.ECAP + (size_t)d.QCAP) * 16 : fd_lu_end;
+  o = build_end;
+  if (vec_end > o) o = vec_end;
+  if (lu_end > o) o = lu_end;
 #undef PPN_TAKE
-  return o;
+  return (o + 15) & ~(size_t)15;
 }

@@ -81,6 +81,10 @@ struct ppn_engine {
   hipStream_t stream = 0;
   size_t lds_bytes = 0;
   size_t lds_small = 0;       // compact carve of the kernels without a solve (K_VALID, K_OBS)
+  // Q plane of the Newton storage (Smem): sized from the chronics unless rules.lu_capacity fixes the storage
+  bool auto_qcap = true;
+  std::vector<int> rowlen_sub, sub_gen_;   // filled-pattern row length of every substation's busbar, production of a substation (-1: none)
+  int pattern_pairs = 0;
   int base_fill = 0;
   std::string err;
   u8* d_actions = nullptr;
@@ -129,79 +133,18 @@ static T* dalloc(ppn_engine* e, size_t n) {
   return (T*)p;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// kernels / launchers
-enum { K_STEP = 0, K_GAMEOVER, K_RESET, K_RUNPF, K_VALID, K_OBS };
-
-struct KArgs {
-  DevCase d;
-  DevState st;
-  const u8* actions;
-  u8* valid;
-  const int *ids, *slots, *t0;
-  void* obs;            // K_OBS output: double or float rows of obs_stride elements
-  int obs_sections, obs_stride, obs_f32;   // 1 minimalist, 2 + AC extras, 3 full observation
-  int sim, auto_reset;
-  const int* perm;      // launch order of the step kernel: workgroup b runs environment perm[b] (null: b)
-};
-
-#ifndef PPN_EMU
-template <int W, int KIND, int NT>
-#ifndef PPN_WAVES_PER_EU
-#define PPN_WAVES_PER_EU 1
-#endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPN_WAVES_PER_EU))) ppn_kernel(const KArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Smem S;
-  ppn_carve(a.d, W, smem, &S, KIND == K_VALID || KIND == K_OBS);
-  const int env = (KIND == K_STEP && a.perm) ? a.perm[blockIdx.x] : (int)blockIdx.x;
-  const int lane0 = threadIdx.x;
-  if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, lane0);
-  else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, env, lane0);
-  else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, lane0);
-  else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, lane0);
-  else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, lane0);
-  else if (KIND == K_OBS) { if (a.obs_f32) body_obs<float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, lane0); else body_obs<double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, lane0); }
-}
-#endif
-
-#ifndef PPN_EMU
-// Launch order of the step kernel.  Environment steps differ in length by an order of magnitude (one 3-iteration solve
-// ... a six-solve cascade ending in a diverging 10-iteration solve and a restart), and a launch of `batch` workgroups
-// over 1024 resident slots ends with its longest chains: started in index order the machine idles ~40 % of the launch.
-// The largest loading (ampere flow / thermal limit) left by the previous step predicts the long ones well enough
-// (overflowed lines -> cuts, re-solves, divergence), so the workgroups are handed out by decreasing loading: a counting
-// sort over 256 loading classes, one workgroup.
-#define PPN_ORDER_BINS 256
-__global__ void __launch_bounds__(1024) ppn_order_kernel(const float* prio, int* perm, int n) {
-  __shared__ int hist[PPN_ORDER_BINS];
-  __shared__ int offs[PPN_ORDER_BINS];
-  const int t = threadIdx.x;
-  if (t < PPN_ORDER_BINS) hist[t] = 0;
-  __syncthreads();
-  auto bin_of = [](float p) {
-    if (!(p == p)) p = 2.5f;                       // NaN loading (a collapsed voltage): treat as heavy
-    int b = (int)((2.5f - p) * (PPN_ORDER_BINS / 2.0f));   // 2.5 -> class 0 (first), 0.5 -> last
-    return b < 0 ? 0 : (b >= PPN_ORDER_BINS ? PPN_ORDER_BINS - 1 : b);
-  };
-  for (int i = t; i < n; i += 1024) atomicAdd(&hist[bin_of(prio[i])], 1);
-  __syncthreads();
-  if (t == 0) { int run = 0; for (int b = 0; b < PPN_ORDER_BINS; ++b) { offs[b] = run; run += hist[b]; } }
-  __syncthreads();
-  for (int i = t; i < n; i += 1024) perm[atomicAdd(&offs[bin_of(prio[i])], 1)] = i;
-}
-#endif
+#include "ppn_kernels.inc"
 
 template <int W, int KIND, int NT>
 static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
 #ifdef PPN_EMU
   (void)timed;
-  std::vector<unsigned char> lds(e->lds_bytes + 64);
+  std::vector<unsigned char> lds(std::max(e->lds_bytes, e->lds_small) + 64);
   unsigned char* base = (unsigned char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
   Smem S;
-  ppn_carve(a.d, W, base, &S);
+  ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS);
   for (int env = 0; env < nblocks; ++env) {
-    memset(base, 0xA5, e->lds_bytes);   // LDS is NOT zero-initialised on the GPU either
+    memset(base, 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
     if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, 0);
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
@@ -445,7 +388,7 @@ extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
     case 0: return d.nS; case 1: return d.nP; case 2: return d.nL; case 3: return d.nl;
     case 4: return d.alen; case 5: return d.obslen; case 6: return e->batch; case 7: return (int32_t)e->lds_bytes;
     case 8: return d.NB; case 9: return d.LUCAP; case 10: return (int32_t)e->chronics.size(); case 11: return e->base_fill;
-    case 12: return d.ECAP; case 13: return d.MCAP; case 14: return d.TCAP;
+    case 12: return d.ECAP; case 13: return d.MCAP; case 14: return d.TCAP; case 15: return d.QCAP;
     default: return -1;
   }
 }
@@ -625,7 +568,8 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     d.TCAP = ((int)(base_tri * grow) + 256 + 15) & ~15;
     if (d.MCAP > 65000 || d.TCAP > 21000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "schedule capacity exceeds 16-bit offsets"); }
   }
-  // filled-pattern capacity (entries); the LU storage holds 2x2 blocks: LUCAP = 4 * ECAP doubles
+  // filled-pattern capacity (entries).  Newton storage: a P plane of ECAP half blocks + a Q plane of QCAP half blocks (Smem);
+  // QCAP starts at the safe maximum and is sized from the chronics by size_q_plane() once they are loaded
   int ecap = r->lu_capacity > 0 ? (r->lu_capacity + 3) / 4 : 0;
   if (ecap <= 0) {
     const double extra = (NB > nS) ? (double)(NB - nS) / nS : 0.0;   // share of busbars that may be split off
@@ -636,23 +580,28 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     ecap = (NB > nS) ? (int)(pairs * (1.15 + 1.0 * extra)) + 16 : pairs;
   }
   d.ECAP = (ecap + 7) & ~7;
-  d.LUCAP = 4 * d.ECAP;
+  d.QCAP = d.ECAP;
+  d.LUCAP = 2 * (d.ECAP + d.QCAP);
+  e->auto_qcap = !(r->lu_capacity > 0);
+  e->pattern_pairs = pairs;
+  e->sub_gen_ = sub_gen;
+  {
+    std::vector<int> pos(nS);
+    for (int p = 0; p < nS; ++p) pos[order[p]] = p;
+    e->rowlen_sub.assign(nS, 0);
+    for (int s_ = 0; s_ < nS; ++s_) for (int j = 0; j < nS; ++j) e->rowlen_sub[s_] += filled[pos[s_]][j];
+  }
   if (d.ECAP > 16000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds 16-bit entry indices"); }
   {   // schedule cache blob of one environment
     size_t o = 64;                      // header: 16 ints
     auto take = [&](int* off, size_t bytes) { *off = (int)o; o += (bytes + 15) & ~(size_t)15; };
     take(&d.co_sig, (size_t)d.ntopo); take(&d.co_r2s, (size_t)nrows); take(&d.co_i2r, (size_t)NB * 2);
-    take(&d.co_ediag, (size_t)NB * 2); take(&d.co_ydiag, (size_t)NB * 2);
+    take(&d.co_ediag, (size_t)NB * 2); take(&d.co_ydiag, (size_t)NB * 2); take(&d.co_rowptr, (size_t)(NB + 1) * 2);
     take(&d.co_le4, (size_t)nl * 8); take(&d.co_ly4, (size_t)nl * 8);
     take(&d.co_ymeta, (size_t)d.YCAP * 4); take(&d.co_lvl, (size_t)(nlev + 1) * 8);
     take(&d.co_tail, 32 + 512);         // dense tail: up to 16 bus indices (+pad), up to 16 x 16 entry map (u16)
-    take(&d.co_fill, (size_t)PPN_FILL_REGS * 64 * 2);   // fill-in entries of the pattern (the ones no Ybus entry covers)
+    take(&d.co_fill, (size_t)PPN_FILL_REGS * 64 * 4);   // fill-in entries of the pattern (the ones no Ybus entry covers)
     d.cache_stride = (int)o;
-  }
-  { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, nullptr, &tmp); e->lds_small = ppn_carve(d, e->W, nullptr, &tmp, true); }
-  if (e->lds_bytes > 160 * 1024) {
-    free_all(e); delete e;
-    return fail(nullptr, PPN_E_CAPACITY, "case needs %zu bytes of LDS per environment (limit 160 KiB)", e->lds_bytes);
   }
   d.bus_gs = upload(e, gs, e->allocs); d.bus_bs = upload(e, bs, e->allocs); d.bus_kv = upload(e, kv, e->allocs);
   d.vm0 = upload(e, vm0, e->allocs); d.va0 = upload(e, va0, e->allocs);
@@ -692,6 +641,11 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (R.solver != PPN_SOLVER_NEWTON && R.solver != PPN_SOLVER_FDXB) return bad("solver must be NEWTON or FDXB");
   if (R.max_it <= 0) R.max_it = (R.solver == PPN_SOLVER_NEWTON) ? 10 : 25;
   if (!(R.tol > 0)) R.tol = 1e-6;
+  { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, e->newton ? 1 : 0, nullptr, &tmp); e->lds_small = ppn_carve(d, e->W, 0, nullptr, &tmp, true); }
+  if (e->lds_bytes > 160 * 1024) {
+    free_all(e); delete e;
+    return fail(nullptr, PPN_E_CAPACITY, "case needs %zu bytes of LDS per environment (limit 160 KiB)", e->lds_bytes);
+  }
 
   if (alloc_state(e, &e->st, (size_t)batch) || alloc_state(e, &e->sim, (size_t)batch)) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation failed: %s", dev_err()); }
   e->base_cache = dalloc<u8>(e, (size_t)d.cache_stride); e->base_tri = dalloc<u64>(e, (size_t)d.TCAP);
@@ -741,6 +695,49 @@ extern "C" int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* 
 }
 
 static int index_of(const std::vector<int>& v, int x) { for (size_t i = 0; i < v.size(); ++i) if (v[i] == x) return (int)i; return -1; }
+
+// Q plane of the Newton storage (Smem): a bus has a Q row iff it is a PQ bus -- no production at its busbar, or one that is
+// switched off (prods_v <= 0) in the row being played.  Without spare busbars (NB == nS: every element stays with its
+// substation) the largest need over every row of every loaded chronic, realised and planned series, is an exact bound (buses
+// that lose all their lines only lower it); with spare busbars the same fraction of the filled pattern plus a margin is
+// reserved.  A solve that needs more (state written through ppn_write, an unusual split) reports PPN_FLAG_ENGINE_CAPACITY
+// like any other capacity; rules.lu_capacity reserves the full planes.
+static int size_q_plane(ppn_engine* e) {
+  DevCase& d = e->dc;
+  if (!e->newton || !e->auto_qcap) return PPN_OK;
+  const int nS = d.nS, nP = d.nP;
+  std::vector<int> gen_sub(nP);
+  for (int s_ = 0; s_ < nS; ++s_) if (e->sub_gen_[s_] >= 0) gen_sub[e->sub_gen_[s_]] = s_;
+  long base = 0;
+  for (int s_ = 0; s_ < nS; ++s_) if (e->sub_gen_[s_] < 0) base += e->rowlen_sub[s_];
+  long worst = base;
+  for (const HostChronic& h : e->chronics) {
+    for (const std::vector<float>* series : {&h.pv, &h.pvp}) {
+      for (int t = 0; t < h.T; ++t) {
+        long need = base;
+        const float* v = series->data() + (size_t)t * nP;
+        for (int g = 0; g < nP; ++g) if (v[g] <= 0.0f) need += e->rowlen_sub[gen_sub[g]];
+        worst = std::max(worst, need);
+      }
+    }
+  }
+  int qcap;
+  if (d.NB == nS) qcap = (int)worst;
+  else qcap = (int)(((double)worst / e->pattern_pairs + 0.12) * d.ECAP) + 8;
+  if (getenv("PPN_QCAP_FULL")) qcap = d.ECAP;
+  qcap = std::min(d.ECAP, (qcap + 7) & ~7);
+  d.QCAP = qcap;
+  d.LUCAP = 2 * (d.ECAP + d.QCAP);
+  Smem tmp;
+  e->lds_bytes = ppn_carve(d, e->W, 1, nullptr, &tmp);
+#ifndef PPN_EMU
+  int rc_attr = 0;
+  switch (e->W) { case 1: rc_attr = set_lds_attr<1>(e->lds_bytes); break; case 2: rc_attr = set_lds_attr<2>(e->lds_bytes); break;
+                  default: rc_attr = set_lds_attr<4>(e->lds_bytes); }
+  if (rc_attr) return fail(e, PPN_E_HIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, dev_err());
+#endif
+  return PPN_OK;
+}
 
 static int sync_chronics(ppn_engine* e) {
   if (!e->chronics_dirty) return PPN_OK;
@@ -795,7 +792,7 @@ static int sync_chronics(ppn_engine* e) {
   d.c_roll2 = upload(e, roll2, e->chronic_allocs);
   if (e->mem_failed) { e->mem_failed = false; return fail(e, PPN_E_HIP, "chronic upload failed: %s", dev_err()); }
   e->chronics_dirty = false;
-  return PPN_OK;
+  return size_q_plane(e);
 }
 
 static KArgs make_args(ppn_engine* e, bool sim_state) {
