@@ -172,8 +172,12 @@ def main():
     torch.cuda.synchronize()
     aptr = actions.data_ptr()
 
+    # auto_reset = 2 (include/ppn.h, ppn_step): an episode that ends is restarted at the head of the environment's NEXT step
+    # launch instead of at the tail of this one; eng.sync() settles the restarts still owed, so that every restart of the K
+    # timed steps is inside the timed region
+    AUTO_RESET = int(os.environ.get('PPN_BENCH_AUTO_RESET', '2'))
     for _ in range(args.warmup):
-        eng.step_device(aptr, auto_reset=True)
+        eng.step_device(aptr, auto_reset=AUTO_RESET)
     eng.sync()
     ns0, ni0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
     eng.kernel_time(reset=True)
@@ -190,7 +194,7 @@ def main():
         def exchange():
             dist.scatter(actions, all_actions, src=0)                # [B x action_length] u8 to every rank
             torch.cuda.synchronize()
-            eng.step_device(aptr, auto_reset=True)
+            eng.step_device(aptr, auto_reset=AUTO_RESET)
             eng.read_into_device('DONE', d_done.data_ptr(), d_done.numel())
             eng.read_into_device('FLAG', d_flag.data_ptr(), 4 * d_flag.numel())
             eng.read_into_device('REWARD', d_rew.data_ptr(), 8 * d_rew.numel())
@@ -208,7 +212,7 @@ def main():
         if exchange is not None:
             exchange()
         else:
-            eng.step_device(aptr, auto_reset=True)
+            eng.step_device(aptr, auto_reset=AUTO_RESET)
     eng.sync()
     torch.cuda.synchronize()
     if use_dist:
@@ -258,7 +262,7 @@ def main():
                                        'reward every step' if exchange is not None else
                                        'env-sharded x%d, no collective in the step loop') % world,
                        'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
-                       'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now,
+                       'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now, 'auto_reset_mode': AUTO_RESET,
                        'mean_cascade_depth_last_step': depth_now},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
@@ -274,8 +278,9 @@ def main():
             eng.sync()
             t_h = time.perf_counter()
             for _ in range(n_host):
-                eng.step(host_actions, auto_reset=True)
+                eng.step(host_actions, auto_reset=AUTO_RESET)
                 eng.read('DONE'); eng.read('FLAG'); eng.read('REWARD')
+            eng.sync()
             out['config']['host_boundary_env_steps_per_s'] = B * n_host / (time.perf_counter() - t_h)
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -150,7 +150,7 @@ typedef enum ppn_field {
   PPN_F_DONE,              /* u8 [1]                                                           */
   PPN_F_FLAG,              /* i32 [1]   PPN_FLAG_*                                             */
   PPN_F_ILLEGAL,           /* i32 [1]   PPN_ILL_* bits of the last step                        */
-  PPN_F_CASCADE_DEPTH,     /* i32 [1]   depth reached by the last cascade                      */
+  PPN_F_CASCADE_DEPTH,     /* i32 [1]   depth reached by the cascade of the last step          */
   PPN_F_N_SOLVES,          /* i32 [1]   cumulative number of load-flow solves                  */
   PPN_F_N_ITERS,           /* i32 [1]   cumulative solver iterations (NR its / FD half-its)     */
   PPN_F_CHRONIC_SLOT,      /* i32 [1]                                                          */
@@ -214,8 +214,14 @@ int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* c
 /* Game.step for every environment that is not done (game.py:799-885).  actions: u8 [batch x action_len],
  * host pointer (actions_on_device=0) or device pointer (1).  simulate!=0: Game.simulate (game.py:887-943):
  * the step runs on a scratch copy of the state and results are read with ppn_read(..., from_simulation=1).
- * auto_reset!=0: environments that end the step done are passed through process_game_over (game.py:762-780)
- * in the same call; PPN_F_DONE/FLAG still report the step's outcome. */
+ * auto_reset = 1: environments that end the step done are passed through process_game_over (game.py:762-780)
+ * in the same call; PPN_F_DONE/FLAG still report the step's outcome.
+ * auto_reset = 2: the same outcome, scheduled differently -- the restart of an environment that ends is DEFERRED to the next
+ * ppn_step(auto_reset = 2) launch, where it runs right before that environment's step (the restart then is the head of a short
+ * chain, the first step of a fresh episode, instead of the tail of the longest chain of the launch, a cascade that ended in a
+ * diverging solve).  Anything that looks at the state in between (ppn_sync, ppn_read of a non-report field, ppn_write,
+ * ppn_read_observation, a step in another mode, ...) settles the owed restarts first, so callers observe exactly what
+ * auto_reset = 1 would have shown them. */
 int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
              int32_t auto_reset);
 /* Topology-action search (the reference's search agents call RunEnv.simulate once per candidate,

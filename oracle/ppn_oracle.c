@@ -596,8 +596,8 @@ static int orc_cascade(const OCase* c, OEnv* e, int rec_ev) {
     if (!cut) break;
   }
   if (!rc) for (int l = 0; l < nl; ++l) e->soft[l] = over[l] ? e->soft[l] + 1 : 0;
-  e->depth = solves - 1; e->nsolve += solves; e->succ = (rc == 0);
-  if (rec_ev) e->src = rc;
+  e->nsolve += solves; e->succ = (rc == 0);
+  if (rec_ev) { e->depth = solves - 1; e->src = rc; }
   free(over);
   return rc;
 }

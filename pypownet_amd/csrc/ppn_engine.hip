@@ -72,6 +72,8 @@ struct ppn_engine {
   bool mem_failed = false;    // sticky: a device allocation or an upload failed (checked by the entry point that caused it)
   bool newton = false;        // rules: AC mode with the Newton-Raphson solver -> the NT = 1 kernels
   bool maybe_dead = true;     // some environment may be over at the next ppn_step (see ppn_step)
+  float restart_prio = 1.3f;      // (PPN_RESTART_PRIO: where in the launch order an environment that owes its restart starts)
+  bool pending_restart = false;   // auto_reset = 2: environments that ended the last step still owe their restart (settle_restarts)
   // shared schedule of the reference topology (DevCase::b_*): allocated by ppn_create, filled from the first environment
   // of the first ppn_reset (whose solve built it), then handed to every later launch
   u8* base_cache = nullptr; u64 *base_tri = nullptr, *base_pair = nullptr; unsigned* base_piv = nullptr;
@@ -145,7 +147,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
-    if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, env, 0);
+    if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, a.restart_prio, env, 0);
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
@@ -655,6 +657,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   e->d_valid = dalloc<u8>(e, batch);
   e->d_perm = dalloc<int>(e, batch);
   { const char* v = getenv("PPN_LAUNCH_ORDER"); if (v && v[0] == '0') e->order_launches = false; }
+  { const char* v = getenv("PPN_RESTART_PRIO"); if (v) e->restart_prio = (float)atof(v); }
   e->d_ids = dalloc<int>(e, (size_t)3 * batch);
   e->d_obs = dalloc<double>(e, (size_t)batch * d.obslen);
   if (e->mem_failed) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation or upload failed: %s", dev_err()); }
@@ -803,9 +806,21 @@ static KArgs make_args(ppn_engine* e, bool sim_state) {
   return a;
 }
 
+// Deferred auto-reset (ppn_step with auto_reset = 2): the restart of an episode that ended is owed to the NEXT step launch.
+// Whatever looks at the state in between -- ppn_sync, a read of anything but the step's report fields, a write, a simulation,
+// a step in another mode -- settles the debt first with the plain process_game_over kernel.
+static int settle_restarts(ppn_engine* e) {
+  if (!e->pending_restart) return PPN_OK;
+  e->pending_restart = false;
+  KArgs a = make_args(e, false);
+  if (launch<K_GAMEOVER>(e, a, e->batch)) return fail(e, PPN_E_HIP, "game-over kernel launch failed: %s", dev_err());
+  return PPN_OK;
+}
+
 extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* chronic_slot, const int32_t* t0) {
   enter(e);
   if (!e) return PPN_E_INVALID;
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }
   int rc = sync_chronics(e);
   if (rc) return rc;
   if (!env_ids) n = e->batch;
@@ -888,9 +903,12 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
     if (dev_h2d(e->d_actions, actions, (size_t)e->batch * e->dc.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
     dact = e->d_actions;
   }
+  const int mode = simulate ? 0 : (auto_reset == 2 ? 2 : (auto_reset ? 1 : 0));
+  if (mode != 2) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (simulate) { if (copy_state(e, &e->sim, &e->st)) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err()); }
   KArgs a = make_args(e, simulate != 0);
-  a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = (auto_reset && !simulate) ? 1 : 0;
+  a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = mode;
+  a.restart_prio = e->restart_prio;
 #ifndef PPN_EMU
   if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first
     hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch);
@@ -906,6 +924,7 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
     e->maybe_dead = false;
   }
   if (!a.auto_reset && !simulate) e->maybe_dead = true;
+  if (mode == 2) e->pending_restart = true;
   return PPN_OK;
 }
 
@@ -938,6 +957,7 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
                                        const int32_t* env_ids, int32_t n) {
   enter(e);
   if (!e || !actions || !env_ids || n <= 0) return PPN_E_INVALID;
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }
   for (int c = 0; c < n; ++c) if (env_ids[c] < 0 || env_ids[c] >= e->batch) return fail(e, PPN_E_INVALID, "ppn_simulate_candidates: environment %d out of range", env_ids[c]);
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
   const DevCase& d = e->dc;
@@ -996,6 +1016,7 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
 extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
   enter(e);
   if (!e) return PPN_E_INVALID;
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
   KArgs a = make_args(e, false);
   if (env_mask) {
@@ -1009,6 +1030,7 @@ extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
 extern "C" int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_t* valid) {
   enter(e);
   if (!e || !actions || !valid) return PPN_E_INVALID;
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (dev_h2d(e->d_actions, actions, (size_t)e->batch * e->dc.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
   KArgs a = make_args(e, false);
   a.actions = e->d_actions; a.valid = e->d_valid;
@@ -1020,6 +1042,7 @@ extern "C" int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_
 extern "C" int ppn_runpf_batch(ppn_engine* e) {
   enter(e);
   if (!e) return PPN_E_INVALID;
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }
   KArgs a = make_args(e, false);
   if (launch<K_RUNPF>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "runpf kernel launch failed: %s", dev_err());
   return PPN_OK;
@@ -1028,6 +1051,7 @@ extern "C" int ppn_runpf_batch(ppn_engine* e) {
 extern "C" int ppn_sync(ppn_engine* e) {
   enter(e);
   if (!e) return PPN_E_INVALID;
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }
 #ifndef PPN_EMU
   if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
 #endif
@@ -1069,6 +1093,7 @@ extern "C" int ppn_read_observation(ppn_engine* e, int32_t layout, int32_t as_f3
                                     int32_t from_simulation) {
   enter(e);
   if (!e || !dst || layout < 0 || layout > 2) return PPN_E_INVALID;
+  if (from_simulation == 0) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read_observation: no candidates have been simulated");
   const size_t B = (from_simulation == 2) ? (size_t)e->n_cand : (size_t)e->batch;
   const int len = obs_length(e->dc, layout);
@@ -1096,6 +1121,12 @@ extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int
   const DevState& s = (from_simulation == 2) ? e->cand : (from_simulation ? e->sim : e->st);
   const size_t B = (from_simulation == 2) ? (size_t)e->n_cand : (size_t)e->batch;
   if (f == PPN_F_OBSERVATION) return ppn_read_observation(e, 0, 0, dst, bytes, to_host, from_simulation);
+  {   // the report of the last step is what it is; everything else shows the restarted episode
+    const bool report = f == PPN_F_DONE || f == PPN_F_FLAG || f == PPN_F_ILLEGAL || f == PPN_F_REWARD || f == PPN_F_ILLEGAL_COUNTS ||
+                        f == PPN_F_ACTION_SWITCHES || f == PPN_F_CASCADE_DEPTH || f == PPN_F_LINE_EVENTS || f == PPN_F_SOLVE_OUTCOME ||
+                        (int)f == 100 /* phase counters of the profiling build */;
+    if (!report && from_simulation == 0) { int rcs = settle_restarts(e); if (rcs) return rcs; }
+  }
   FieldInfo fi; bool w;
   if (!field_info(e, f, &fi, &w)) return fail(e, PPN_E_INVALID, "ppn_read: unknown field %d", (int)f);
   const size_t need = fi.elem * fi.n * B;
@@ -1108,6 +1139,7 @@ extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int
 extern "C" int ppn_write(ppn_engine* e, ppn_field f, const void* src, size_t bytes) {
   enter(e);
   if (!e || !src) return PPN_E_INVALID;
+  if ((int)f != 100) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   FieldInfo fi; bool w;
   if (!field_info(e, f, &fi, &w) || !w) return fail(e, PPN_E_INVALID, "ppn_write: field %d is not writable", (int)f);
   const size_t need = fi.elem * fi.n * (size_t)e->batch;

@@ -173,12 +173,14 @@ class Engine(object):
         return a
 
     def step(self, actions, auto_reset=False):
+        """auto_reset: False | True (environments that end are restarted in the same launch) | 2 (same outcome, the restart
+        deferred to the next step launch: include/ppn.h, ppn_step)."""
         a = self._actions(actions)
-        self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 0, 1 if auto_reset else 0), 'ppn_step')
+        self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 0, int(auto_reset)), 'ppn_step')
 
     def step_device(self, actions_ptr, auto_reset=False):
         """actions_ptr: device address of a uint8 [batch x action_len] buffer (e.g. torch_tensor.data_ptr())."""
-        self._check(self._lib.ppn_step(self._h, C.c_void_p(int(actions_ptr)), 1, 0, 1 if auto_reset else 0), 'ppn_step')
+        self._check(self._lib.ppn_step(self._h, C.c_void_p(int(actions_ptr)), 1, 0, int(auto_reset)), 'ppn_step')
 
     def simulate(self, actions):
         a = self._actions(actions)

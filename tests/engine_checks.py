@@ -585,3 +585,54 @@ def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='new
         np.testing.assert_allclose(eng.read('AMPS'), orc.read('AMPS'), rtol=0, atol=1e-5)
     return dict(solves=int(orc.read('N_SOLVES').astype(np.int64).sum()), done=n_done, worst=worst,
                 slots=len(set(int(s) for s in orc.read('CHRONIC_SLOT'))))
+
+
+def check_deferred_restart(lib_path, envname='default118', steps=30, batch=24, bench_limits=True, max_active_buses=118, seed=3,
+                           random_acts=False):
+    """ppn_step(auto_reset = 2) -- the restart of an episode that ended is owed to the next step launch -- shows callers exactly
+    what auto_reset = 1 (restart fused into the same launch) shows them: the report fields of every step, and, whenever the
+    state is looked at, every state field bit for bit.  Also against the C oracle (flags and chronic positions)."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    kw = {}
+    if bench_limits:
+        with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
+            kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
+    ekw = dict(kw)
+    if max_active_buses:
+        ekw['max_active_buses'] = max_active_buses
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **ekw)      # deferred
+    b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **ekw)      # fused
+    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics, **kw)
+    slots, t0 = default_assignment(np.arange(batch) * 5, chronics)
+    for e in (a, b, orc):
+        e.reset(chronic_slot=slots, t0=t0)
+    rng = np.random.default_rng(seed)
+    report = ('DONE', 'FLAG', 'ILLEGAL', 'REWARD', 'CASCADE_DEPTH', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'ILLEGAL_COUNTS', 'ACTION_SWITCHES')
+    state = ('VM', 'VA', 'PG', 'QG', 'PF', 'AMPS', 'LINES_STATUS', 'PRODS_NODES', 'LINES_OR_NODES', 'RECONNECTABLE', 'LINE_COOLDOWN',
+             'NODE_COOLDOWN', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES', 'N_ITERS', 'N_LOADS_CUT', 'BUS_TYPE')
+    n_done = 0
+    for t in range(steps):
+        acts = random_actions(case, rng, batch) if random_acts else np.zeros((batch, case.action_length), dtype=np.uint8)
+        a.step(acts, auto_reset=2)
+        b.step(acts, auto_reset=True)
+        orc.step(acts, auto_reset=True)
+        for f in report:       # (reading these does not settle the owed restarts)
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
+        assert np.array_equal(a.read('DONE'), orc.read('DONE')) and np.array_equal(a.read('FLAG'), orc.read('FLAG'))
+        n_done += int(b.read('DONE').sum())
+        if t % 4 == 3 or t == steps - 1:      # look at the state (this settles): identical to the fused engine's
+            for f in state:
+                assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
+            assert np.array_equal(a.observations(), b.observations(), equal_nan=True)
+            assert np.array_equal(a.read('CHRONIC_ROW'), orc.read('CHRONIC_ROW'))
+        if t % 7 == 5:                         # a simulation in between settles as well, and leaves no trace
+            a.simulate(acts)
+            b.simulate(acts)
+            assert np.array_equal(a.read('FLAG', simulation=True), b.read('FLAG', simulation=True))
+    assert n_done > 0
+    return n_done

@@ -124,3 +124,9 @@ def test_emu_full_size_check_at_small_size(emu_lib):
     assert st['slots'] >= 2
     st = ec.check_full_size_lockstep(emu_lib, 'default118', 6, 12, 4, bench_limits=True, max_active_buses=118, game_over_mode='hard')
     assert st['done'] > 0
+
+
+def test_emu_deferred_restart_equals_fused(emu_lib):
+    assert ec.check_deferred_restart(emu_lib, steps=16, batch=6) > 0
+    assert ec.check_deferred_restart(emu_lib, 'default14_for_tests_alpha', steps=40, batch=8, bench_limits=False, max_active_buses=0,
+                                     random_acts=True) > 0

@@ -99,6 +99,13 @@ def test_gpu_random_chronic_looping():
     ec.check_random_chronic_looping(HIP, batch=96, steps=40)
 
 
+def test_gpu_deferred_restart_equals_fused():
+    """ppn_step(auto_reset = 2), the mode bench.py steps in, against the fused restart and the C oracle."""
+    assert ec.check_deferred_restart(HIP, steps=40, batch=256) > 100
+    assert ec.check_deferred_restart(HIP, 'default14_for_tests_alpha', steps=60, batch=64, bench_limits=False, max_active_buses=0,
+                                     random_acts=True) > 0
+
+
 def test_gpu_config1_default14_dc_1000_steps():
     """BASELINE.json configs[0] through the HIP engine: default14 in DC mode, do-nothing, 1000 timesteps across the end of
     the first chronic, against the numpy restatement step by step."""

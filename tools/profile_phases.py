@@ -43,13 +43,14 @@ def main():
         acts = [random_node_splitting(case, rng, B) for _ in range(8)]
     else:
         acts = [act]
-    eng.step(acts[0], auto_reset=True)
+    AR = int(os.environ.get('PPN_BENCH_AUTO_RESET', '2'))
+    eng.step(acts[0], auto_reset=AR)
     zero = np.zeros((B, 32), dtype=np.int64)
     eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
     eng.kernel_time(reset=True)
     s0, i0 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
     for k in range(steps):
-        eng.step(acts[(k + 1) % len(acts)], auto_reset=True)
+        eng.step(acts[(k + 1) % len(acts)], auto_reset=AR)
     eng.sync()
     s1, i1 = eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum()
     out = np.zeros((B, 32), dtype=np.int64)
@@ -69,7 +70,7 @@ def main():
     print('step kernel body: %.0f cyc and %.1f us per env-step -> shader clock %.0f MHz under load'
           % (body_c / (B * steps), body_w / (B * steps) * 1e6, body_c / body_w * 1e-6))
     print('step kernel: %.3f ms per launch (HIP events, %d launches); mean resident environments = sum of body wall times / '
-          'kernel time = %.0f (of %d slots = 256 CUs x 4)' % (kt[0] / kt[1], kt[1], body_w * 1e3 / kt[0], 1024))
+          'kernel time = %.0f (of %d slots = 256 CUs x floor(160 KiB / LDS per environment))' % (kt[0] / kt[1], kt[1], body_w * 1e3 / kt[0], 256 * (163840 // eng.lds_bytes)))
 
 
 if __name__ == '__main__':
