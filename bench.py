@@ -103,7 +103,9 @@ def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
         if el > budget_s or steps >= 4000:
             break
     out = {'value': nb * steps / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-           'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle with OpenMP over envs' % (nb, steps, el)}
+           'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle with OpenMP over envs' % (nb, steps, el),
+           'note': 'UNOPTIMISED port: the checker (row-wise LU with a dense accumulator, symbolic work redone in every solve), '
+                   'not a KLU-class refactorising CPU solver -- the GPU / CPU ratio says nothing about kernel quality'}
     # the "reference-equivalent Python backend" -- the numpy/scipy restatement of the PYPOWER path
     # (scipy.sparse + SuperLU, the library class the reference uses), one environment on one host core, same workload
     try:
@@ -123,6 +125,124 @@ def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
     return out
 
 
+# SURVEY.md 8d algorithmic bytes per env-step of the other configurations: (B_io, B per Newton iteration, B per fast-decoupled
+# half-iteration, B per fast-decoupled refactorisation)
+BYTES_8D = {'default14': (2.6e3, 9.0e3, 9.0e3 * 22.0 / 72.0, 9.0e3 * 25.0 / 72.0),      # (@14 the FD figures are scaled from @118)
+            'default118': (B_IO, B_IT_NR, 22.0e3, 25.0e3)}
+
+
+def load_env_fixture(envname, solver):
+    import yaml
+    from pypownet_amd.case import Case
+    from pypownet_amd.chronic import Chronic
+    d = os.path.join(ROOT, 'tests', 'golden', 'envs', envname, 'level0')
+    case = Case.from_file(os.path.join(d, 'reference_grid.json'))
+    with open(os.path.join(d, 'configuration.yaml')) as f:
+        conf = yaml.safe_load(f)
+    conf['solver'] = solver
+    cdir = os.path.join(d, 'chronics')
+    chronics = [Chronic(os.path.join(cdir, c)) for c in sorted(os.listdir(cdir))]
+    return case, conf, chronics
+
+
+def limits_110(case):
+    with open(os.path.join(ROOT, 'tests', 'golden', 'envs', ENV_NAME, 'bench_limits_110.json')) as f:
+        lim = np.asarray(json.load(f)['limits_a'], dtype=np.float64)
+    assert lim.shape == (case.nl,)
+    return lim
+
+
+def random_node_splitting(case, rng, batch):
+    """RandomNodeSplitting-style actions (reference pypownet/agent.py:116-158): one random substation
+    per environment gets a random configuration of its switches."""
+    acts = np.zeros((batch, case.action_length), dtype=np.uint8)
+    subs = rng.integers(case.nS, size=batch)
+    for b in range(batch):
+        idx = np.asarray(case.mapping_array[int(subs[b])], dtype=int)
+        acts[b, idx] = rng.integers(0, 2, size=len(idx))
+    return acts
+
+
+def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=None, split=False, max_active=None, warmup=4,
+                histogram=False):
+    """One of the other single-GPU configurations of BASELINE.json, timed like the headline (device-resident actions, K steps
+    between synchronisations, step-kernel time from HIP events) and priced with its own SURVEY.md 8d byte count."""
+    import torch
+    from pypownet_amd.engine import Engine
+    case, conf, chronics = load_env_fixture(envname, solver)
+    kw = {}
+    if max_active:
+        kw['max_active_buses'] = max_active
+    eng = Engine(case, conf, batch, device=device, chronics=chronics, thermal_limits=limits, **kw)
+    slots, t0 = env_assignment(0, batch, chronics)
+    eng.reset(chronic_slot=slots, t0=t0)
+    rng = np.random.default_rng(1234)
+    n_act = 8 if split else 1
+    acts = [torch.from_numpy(random_node_splitting(case, rng, batch) if split else
+                             np.zeros((batch, case.action_length), dtype=np.uint8)).to('cuda:%d' % device) for _ in range(n_act)]
+    torch.cuda.synchronize()
+    for k in range(warmup):
+        eng.step_device(acts[k % n_act].data_ptr(), auto_reset=auto_reset)
+    eng.sync()
+    s0, i0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
+    eng.kernel_time(reset=True)
+    n_done, depth_hist = 0, np.zeros(8, dtype=np.int64)
+    t = time.perf_counter()
+    for k in range(steps):
+        eng.step_device(acts[k % n_act].data_ptr(), auto_reset=auto_reset)
+        if histogram:      # (report fields: reading them does not settle the deferred restarts; it does synchronise)
+            n_done += int(eng.read('DONE').sum())
+            depth_hist += np.bincount(np.minimum(eng.read('CASCADE_DEPTH'), 7), minlength=8)
+    eng.sync()
+    el = time.perf_counter() - t
+    kms, kn = eng.kernel_time(reset=True)
+    s1, i1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
+    n_solve, n_it = float(s1 - s0) / (batch * steps), float(i1 - i0) / max(float(s1 - s0), 1.0)
+    b_io, b_nr, b_fd, b_fact = BYTES_8D[envname]
+    b_step = b_io + n_solve * (n_it * b_nr if solver == 'newton' else n_it * b_fd + b_fact)
+    k_s = (kms / 1e3) / max(kn, 1)
+    out = {'config': name, 'env': envname, 'solver': solver, 'batch': batch, 'steps': steps,
+           'env_steps_per_s': batch * steps / el, 'ms_per_step': 1e3 * el / steps, 'step_kernel_ms': 1e3 * k_s,
+           'solves_per_step': n_solve, 'iters_per_solve': n_it, 'lds_bytes_per_env': eng.lds_bytes,
+           'algorithmic_bytes_per_env_step': b_step, 'roofline_frac': batch * b_step / k_s / 1e9 / HBM_PEAK_GBS,
+           'engine_capacity_flags_last_step': int((eng.read('FLAG') == 4).sum())}
+    if split:
+        out['illegal_fraction_last_step'] = float((eng.read('ILLEGAL') != 0).mean())
+    if histogram:
+        out['note'] = 'DONE / CASCADE_DEPTH read back every step for the statistics: the rate includes that synchronisation'
+        out['game_over_rate'] = n_done / float(batch * steps)
+        out['cascade_depth_histogram'] = [int(v) for v in depth_hist]
+    eng.close()
+    return out
+
+
+def other_configs(device, auto_reset, steps):
+    """BASELINE.json configs[1], configs[2] with the reference's solver, the one-GPU share of configs[4], the large-batch point
+    and the SURVEY.md 8d limit rule of configs[2] -- one entry each in the bench line (`other_configs`)."""
+    case118, _, _ = load_env_fixture(ENV_NAME, 'newton')
+    lim = bench_limits(case118)
+    out = []
+
+    def add(*a, **kw):
+        try:
+            out.append(side_config(*a, **kw))
+        except Exception as ex:      # a side measurement must never take the bench line down
+            out.append({'config': a[0], 'error': str(ex)})
+    add('configs[1]: default14 AC Newton-Raphson, batch 1024, do-nothing', 'default14', 'newton', 1024, steps, device, auto_reset)
+    add('configs[1] at a batch that fills the GPU: default14 AC Newton-Raphson, batch 16384', 'default14', 'newton', 16384, steps,
+        device, auto_reset)
+    add('configs[2] with the reference solver: default118 fast-decoupled XB, batch 4096, cascade limits', ENV_NAME, 'fdxb', 4096,
+        steps, device, auto_reset, limits=lim, max_active=case118.nS)
+    add('configs[2] / configs[3] at 32768 environments on one GPU', ENV_NAME, 'newton', 32768, max(8, steps // 3), device, auto_reset,
+        limits=lim, max_active=case118.nS)
+    add('configs[4] share of one GPU: default118 AC Newton-Raphson, random node splitting every step, batch 1024, every busbar may '
+        'be active (W = 4 kernels, schedule rebuilt on every accepted switch)', ENV_NAME, 'newton', 1024, steps, device, auto_reset,
+        limits=lim, split=True)
+    add('configs[2] with the limit rule of SURVEY.md 8d config 3: limit = max(50, 1.10 x I(t = 0))', ENV_NAME, 'newton', 4096, steps,
+        device, auto_reset, limits=limits_110(case118), max_active=case118.nS, histogram=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -130,6 +250,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the side measurements of the other single-GPU configurations')
     ap.add_argument('--single-controller', action='store_true',
                     help="BASELINE.json configs[3]'s exchange variant: every step rank 0 scatters the actions of ALL "
                          'environments and gathers (done, flag, reward) over RCCL; default: policy per GPU, no collective')
@@ -168,6 +289,11 @@ def main():
                  lu_capacity=int(os.environ.get('PPN_BENCH_LU_CAPACITY', '0')))   # (occupancy experiments only)
     slots, t0 = env_assignment(rank * B, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
+    import zlib
+    crcs = [zlib.crc32(slots.tobytes() + t0.tobytes())]      # which environments this rank plays (checked by the 2-rank test)
+    if use_dist:
+        crcs = [None] * world
+        dist.all_gather_object(crcs, zlib.crc32(slots.tobytes() + t0.tobytes()))
     actions = torch.zeros((B, case.action_length), dtype=torch.uint8, device='cuda:%d' % local_rank)
     torch.cuda.synchronize()
     aptr = actions.data_ptr()
@@ -191,8 +317,18 @@ def main():
         d_rew = torch.empty((B, 5), dtype=torch.float64, device=dev)
         gathered = [torch.empty((B, 3), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
 
+        on_host = backend != 'nccl'      # (gloo smoke mode: the collectives run on host copies)
+        if on_host and rank == 0:
+            all_actions = [t_.cpu() for t_ in all_actions]
+            gathered = [t_.cpu() for t_ in gathered]
+
         def exchange():
-            dist.scatter(actions, all_actions, src=0)                # [B x action_length] u8 to every rank
+            if on_host:
+                recv = torch.empty(actions.shape, dtype=actions.dtype)
+                dist.scatter(recv, all_actions, src=0)
+                actions.copy_(recv)
+            else:
+                dist.scatter(actions, all_actions, src=0)            # [B x action_length] u8 to every rank
             torch.cuda.synchronize()
             eng.step_device(aptr, auto_reset=AUTO_RESET)
             eng.read_into_device('DONE', d_done.data_ptr(), d_done.numel())
@@ -200,7 +336,7 @@ def main():
             eng.read_into_device('REWARD', d_rew.data_ptr(), 8 * d_rew.numel())
             eng.sync()
             res = torch.stack([d_done.double(), d_flag.double(), d_rew.sum(dim=1)], dim=1)
-            dist.gather(res, gathered, dst=0)                        # 24 B per environment back to the controller
+            dist.gather(res.cpu() if on_host else res, gathered, dst=0)      # 24 B per environment back to the controller
         exchange()
 
     if use_dist:
@@ -263,6 +399,7 @@ def main():
                                        'env-sharded x%d, no collective in the step loop') % world,
                        'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
                        'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now, 'auto_reset_mode': AUTO_RESET,
+                       'env_assignment_crc32': crcs,
                        'mean_cascade_depth_last_step': depth_now},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
@@ -282,6 +419,9 @@ def main():
                 eng.read('DONE'); eng.read('FLAG'); eng.read('REWARD')
             eng.sync()
             out['config']['host_boundary_env_steps_per_s'] = B * n_host / (time.perf_counter() - t_h)
+        if world == 1 and not args.no_other_configs and B == BATCH_PER_GPU:
+            eng.close()
+            out['other_configs'] = other_configs(local_rank, AUTO_RESET, max(12, min(40, args.steps)))
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(case, conf, chronics, limits)

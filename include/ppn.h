@@ -254,7 +254,8 @@ int32_t ppn_observation_length(const ppn_engine* e, int32_t layout);
 /* bytes of one environment's field */
 int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation);
 int ppn_write(ppn_engine* e, ppn_field f, const void* src, size_t bytes);   /* whole batch, host pointer */
-int ppn_sync(ppn_engine* e);
+int ppn_sync(ppn_engine* e);        /* settles the restarts a deferred auto-reset owes (ppn_step), then waits for the stream */
+int ppn_wait(ppn_engine* e);        /* waits for the engine's stream only */
 /* HIP stream the engine launches on (void* = hipStream_t), for callers that time with HIP events. */
 void* ppn_stream(ppn_engine* e);
 /* Average / last device time of the dominant kernel measured with HIP events on the engine stream. */

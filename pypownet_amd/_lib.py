@@ -71,7 +71,7 @@ def field_dtype(name):
 EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limits', 'ppn_load_chronic', 'ppn_reset',
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
-           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length']
+           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait']
 
 
 def load_library():
@@ -124,6 +124,9 @@ def bind_signatures(lib, full_abi=True):
     lib.ppn_write.restype = C.c_int
     lib.ppn_sync.argtypes = [vp]
     lib.ppn_sync.restype = C.c_int
+    if full_abi:
+        lib.ppn_wait.argtypes = [vp]
+        lib.ppn_wait.restype = C.c_int
     lib.ppn_stream.argtypes = [vp]
     lib.ppn_stream.restype = vp
     lib.ppn_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -58,7 +58,8 @@ class BatchedRunEnv(object):
         self.first, self.last = shard_range(global_batch, rank, world_size)
         self.batch = self.last - self.first
         self.env_ids = np.arange(self.first, self.last)
-        self.engine = Engine(self.case, self.conf, self.batch, device=local_device(rank) if device is None else device,
+        self.device = local_device(rank) if device is None else int(device)
+        self.engine = Engine(self.case, self.conf, self.batch, device=self.device,
                              chronics=self.chronics, thermal_limits=thermal_limits, **rule_kw)
         self.action_length = self.case.action_length
         self.observation_length = self.case.observation_length
@@ -68,26 +69,98 @@ class BatchedRunEnv(object):
         self.engine.reset(chronic_slot=slots, t0=t0)
         return self.engine.observations()
 
-    def step(self, actions, auto_reset=True, want_obs=True):
-        """actions: uint8 [batch x action_length] of THIS shard.  Returns (obs|None, done, flag, illegal)."""
-        self.engine.step(actions, auto_reset=auto_reset)
-        done, flag, ill = self.engine.read('DONE'), self.engine.read('FLAG'), self.engine.read('ILLEGAL')
-        return (self.engine.observations() if want_obs else None), done.astype(bool), flag, ill
+    # ---- tensors in, tensors out -----------------------------------------------------------------------------------------
+    # Every call below takes either host arrays (numpy: the actions cross PCIe, results come back as numpy) or DEVICE tensors
+    # -- a torch CUDA tensor, or any object that exports ``__dlpack__`` (cupy, jax, ...), which is imported zero-copy with
+    # torch.from_dlpack -- in which case nothing leaves the GPU: the engine reads the actions where they are
+    # (``Engine.step_device``) and writes observations / done / flag / reward into torch CUDA tensors that are returned
+    # (``Engine.read_into_device``, ``Engine.observations_into_device``); those export ``__dlpack__`` themselves.
+    @staticmethod
+    def _as_device_tensor(x):
+        """None if x is host data; else a contiguous torch CUDA uint8 tensor viewing (not copying) x."""
+        if isinstance(x, np.ndarray) or isinstance(x, (list, tuple)):
+            return None
+        import torch
+        if not torch.is_tensor(x):
+            if not hasattr(x, '__dlpack__'):
+                return None
+            x = torch.from_dlpack(x)
+        if not x.is_cuda:
+            return None
+        if x.dtype != torch.uint8:
+            x = (x != 0).to(torch.uint8)
+        return x.contiguous()
+
+    def _device_results(self, want_obs, simulation=False, layout='full', obs_dtype=None):
+        import torch
+        e = self.engine
+        rows = e._n_candidates if int(simulation) == 2 else self.batch
+        dev = 'cuda:%d' % self.device
+        done = torch.empty((rows,), dtype=torch.uint8, device=dev)
+        flag = torch.empty((rows,), dtype=torch.int32, device=dev)
+        ill = torch.empty((rows,), dtype=torch.int32, device=dev)
+        rew = torch.empty((rows, 5), dtype=torch.float64, device=dev)
+        e.read_into_device('DONE', done.data_ptr(), done.numel(), simulation=simulation)
+        e.read_into_device('FLAG', flag.data_ptr(), 4 * flag.numel(), simulation=simulation)
+        e.read_into_device('ILLEGAL', ill.data_ptr(), 4 * ill.numel(), simulation=simulation)
+        e.read_into_device('REWARD', rew.data_ptr(), 8 * rew.numel(), simulation=simulation)
+        obs = None
+        if want_obs:
+            tdt = torch.float32 if obs_dtype in (np.float32, torch.float32) else torch.float64
+            obs = torch.empty((rows, e.observation_length(layout)), dtype=tdt, device=dev)
+            e.observations_into_device(obs.data_ptr(), obs.numel() * obs.element_size(), simulation=simulation, layout=layout,
+                                       dtype=np.float32 if tdt == torch.float32 else np.float64)
+        return obs, done, flag, ill, rew
+
+    def step(self, actions, auto_reset=True, want_obs=True, layout='full', obs_dtype=None):
+        """actions: uint8 [batch x action_length] of THIS shard, host array or device tensor (see above).
+        Returns (obs|None, done, flag, illegal) -- numpy for host actions, torch CUDA tensors for device actions (the engine's
+        stream is synchronised before they are returned)."""
+        t = self._as_device_tensor(actions)
+        if t is None:
+            self.engine.step(actions, auto_reset=auto_reset)
+            done, flag, ill = self.engine.read('DONE'), self.engine.read('FLAG'), self.engine.read('ILLEGAL')
+            obs = None
+            if want_obs:
+                obs = self.engine.observations(layout=layout, dtype=obs_dtype or np.float64)
+            return obs, done.astype(bool), flag, ill
+        assert tuple(t.shape) == (self.batch, self.action_length)
+        self._sync_torch(t)
+        self.engine.step_device(t.data_ptr(), auto_reset=auto_reset)
+        obs, done, flag, ill, _ = self._device_results(want_obs, layout=layout, obs_dtype=obs_dtype)
+        self.engine.wait()         # (the engine stream only: restarts owed by a deferred auto-reset stay owed)
+        return obs, done.bool(), flag, ill
+
+    @staticmethod
+    def _sync_torch(t):
+        """The engine launches on its own HIP stream: work queued on torch's current stream that produces `t` must be done."""
+        import torch
+        torch.cuda.current_stream(t.device).synchronize()
 
     def search(self, candidate_actions, want_obs=False):
         """Topology-action search (what the reference's search agents do with one ``simulate`` call per candidate,
-        pypownet/agent.py:161-325): ``candidate_actions`` uint8 [batch x K x action_length]; every candidate is
-        simulated from the current state of its environment in one launch.  Returns (rewards [batch x K], done
-        [batch x K], flag [batch x K], obs [batch x K x observation_length] | None)."""
-        a = np.ascontiguousarray(candidate_actions, dtype=np.uint8)
-        B, K = a.shape[0], a.shape[1]
-        assert B == self.batch and a.shape[2] == self.action_length
-        env_ids = np.repeat(np.arange(B, dtype=np.int32), K)
+        pypownet/agent.py:161-325): ``candidate_actions`` uint8 [batch x K x action_length], host array or device tensor; every
+        candidate is simulated from the current state of its environment in one launch.  Returns (rewards [batch x K], done
+        [batch x K], flag [batch x K], obs [batch x K x observation_length] | None) -- numpy or torch CUDA tensors like step()."""
+        t = self._as_device_tensor(candidate_actions)
         e = self.engine
-        e.simulate_candidates(a.reshape(B * K, -1), env_ids)
-        obs = e.observations(simulation=2).reshape(B, K, -1) if want_obs else None
-        return (e.read('REWARD', simulation=2).sum(axis=1).reshape(B, K), e.read('DONE', simulation=2).astype(bool).reshape(B, K),
-                e.read('FLAG', simulation=2).reshape(B, K), obs)
+        if t is None:
+            a = np.ascontiguousarray(candidate_actions, dtype=np.uint8)
+            B, K = a.shape[0], a.shape[1]
+            assert B == self.batch and a.shape[2] == self.action_length
+            env_ids = np.repeat(np.arange(B, dtype=np.int32), K)
+            e.simulate_candidates(a.reshape(B * K, -1), env_ids)
+            obs = e.observations(simulation=2).reshape(B, K, -1) if want_obs else None
+            return (e.read('REWARD', simulation=2).sum(axis=1).reshape(B, K), e.read('DONE', simulation=2).astype(bool).reshape(B, K),
+                    e.read('FLAG', simulation=2).reshape(B, K), obs)
+        B, K = int(t.shape[0]), int(t.shape[1])
+        assert B == self.batch and int(t.shape[2]) == self.action_length
+        self._sync_torch(t)
+        e.simulate_candidates_device(t.data_ptr(), np.repeat(np.arange(B, dtype=np.int32), K))
+        obs, done, flag, ill, rew = self._device_results(want_obs, simulation=2)
+        e.sync()
+        return (rew.sum(dim=1).reshape(B, K), done.bool().reshape(B, K), flag.reshape(B, K),
+                obs.reshape(B, K, -1) if want_obs else None)
 
     def rewards(self, do_sum=True, simulation=False):
         """Reward of the last step of every environment, computed on the device with the reference's shipped
@@ -152,9 +225,17 @@ class BatchedRunEnv(object):
         return recv.cpu().numpy()[:self.batch]
 
     def controller_step(self, global_actions=None, root=0, auto_reset=True):
-        """One step of the single-controller mode: scatter the root's [global_batch x action_length] actions, step the
-        shard, gather (done, flag, reward) of every environment on the root.  Returns (done, flag, reward) on the root,
-        None elsewhere.  Observations stay on their GPU (gather_to_root(env.engine.observations()) fetches them)."""
+        """One step of the single-controller mode (BASELINE.json configs[3]): scatter the root's
+        [global_batch x action_length] actions, step the shard, gather (done, flag, reward) of every environment on the root.
+        Returns (done, flag, reward) on the root, None elsewhere.  Observations stay on their GPU
+        (gather_to_root(env.engine.observations()) fetches them).
+        With the "nccl" backend (RCCL over xGMI) the whole exchange is device resident: the root passes a torch CUDA tensor (a
+        host array is uploaded once), every rank receives its rows straight into device memory, the engine reads them there
+        (``Engine.step_device``) and writes done / flag / reward into device tensors that are gathered as they are; the root
+        gets torch CUDA tensors back.  With "gloo" (CPU tests) the same exchange runs through host arrays."""
+        import torch.distributed as dist
+        if self.world_size > 1 and dist.get_backend() == 'nccl':
+            return self._controller_step_device(global_actions, root, auto_reset)
         acts = self.scatter_from_root(global_actions, root=root)
         self.engine.step(acts, auto_reset=auto_reset)
         e = self.engine
@@ -163,6 +244,38 @@ class BatchedRunEnv(object):
         if full is None:
             return None
         return full[:, 0].astype(bool), full[:, 1].astype(np.int32), full[:, 2]
+
+    def _controller_step_device(self, global_actions, root, auto_reset):
+        import torch
+        import torch.distributed as dist
+        dev = 'cuda:%d' % self.device
+        sizes = [shard_range(self.global_batch, r, self.world_size) for r in range(self.world_size)]
+        mx = max(b_ - a_ for a_, b_ in sizes)
+        recv = torch.empty((mx, self.action_length), dtype=torch.uint8, device=dev)
+        parts = None
+        if self.rank == root:
+            ga = global_actions if torch.is_tensor(global_actions) else torch.from_numpy(np.ascontiguousarray(global_actions, dtype=np.uint8))
+            ga = ga.to(dev, non_blocking=True)
+            assert tuple(ga.shape) == (self.global_batch, self.action_length)
+            parts = []
+            for a_, b_ in sizes:
+                p = ga[a_:b_]
+                if b_ - a_ < mx:
+                    p = torch.cat([p, torch.zeros((mx - (b_ - a_), self.action_length), dtype=torch.uint8, device=dev)])
+                parts.append(p.contiguous())
+        dist.scatter(recv, parts, src=root)
+        torch.cuda.current_stream(recv.device).synchronize()         # (the engine launches on its own stream)
+        self.engine.step_device(recv.data_ptr(), auto_reset=auto_reset)      # the first `batch` rows are this shard's
+        _, done, flag, _, rew = self._device_results(False)
+        self.engine.wait()
+        res = torch.zeros((mx, 3), dtype=torch.float64, device=dev)
+        res[:self.batch, 0] = done.double(); res[:self.batch, 1] = flag.double(); res[:self.batch, 2] = rew.sum(dim=1)
+        out = [torch.empty_like(res) for _ in range(self.world_size)] if self.rank == root else None
+        dist.gather(res, out, dst=root)
+        if self.rank != root:
+            return None
+        full = torch.cat([o[:b_ - a_] for o, (a_, b_) in zip(out, sizes)])
+        return full[:, 0] != 0, full[:, 1].to(torch.int32), full[:, 2]
 
     def all_reduce_stats(self, values):
         import torch

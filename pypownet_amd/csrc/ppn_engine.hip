@@ -1058,6 +1058,15 @@ extern "C" int ppn_sync(ppn_engine* e) {
   return PPN_OK;
 }
 
+extern "C" int ppn_wait(ppn_engine* e) {
+  enter(e);
+  if (!e) return PPN_E_INVALID;
+#ifndef PPN_EMU
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
+#endif
+  return PPN_OK;
+}
+
 extern "C" void* ppn_stream(ppn_engine* e) {
 #ifdef PPN_EMU
   (void)e; return nullptr;

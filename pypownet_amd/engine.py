@@ -197,6 +197,13 @@ class Engine(object):
         self._check(self._lib.ppn_simulate_candidates(self._h, a.ctypes.data, 0, ids.ctypes.data_as(C.POINTER(C.c_int32)),
                                                       len(ids)), 'ppn_simulate_candidates')
 
+    def simulate_candidates_device(self, actions_ptr, env_ids):
+        """The same with the candidate actions already on the device (uint8 [n x action_length] at ``actions_ptr``)."""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        self._n_candidates = len(ids)
+        self._check(self._lib.ppn_simulate_candidates(self._h, C.c_void_p(int(actions_ptr)), 1,
+                                                      ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids)), 'ppn_simulate_candidates')
+
     def process_game_over(self, env_mask=None):
         """Game.process_game_over for every dead environment, plus the live ones selected by env_mask."""
         if env_mask is None:
@@ -220,6 +227,10 @@ class Engine(object):
     def sync(self):
         self._check(self._lib.ppn_sync(self._h), 'ppn_sync')
 
+    def wait(self):
+        """Blocks until the engine's stream is idle; unlike sync() it does not settle the restarts a deferred auto-reset owes."""
+        self._check(self._lib.ppn_wait(self._h), 'ppn_wait')
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(0.0), C.c_int64(0)
         self._check(self._lib.ppn_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(n)), 'ppn_kernel_time')
@@ -238,6 +249,15 @@ class Engine(object):
     def read_into_device(self, name, dev_ptr, nbytes, simulation=False):
         fid = _lib.FIELD_ID[name]
         self._check(self._lib.ppn_read(self._h, fid, C.c_void_p(int(dev_ptr)), nbytes, 0, int(simulation)), 'ppn_read')
+
+    def observations_into_device(self, dev_ptr, nbytes, simulation=False, layout='full', dtype=np.float64):
+        """Gathers the observations straight into a caller-owned DEVICE buffer ([rows x observation_length(layout)] of dtype):
+        no host round trip (the policy of a batched agent lives on the GPU)."""
+        self._check(self._lib.ppn_read_observation(self._h, self.OBS_LAYOUTS[layout], 1 if np.dtype(dtype) == np.float32 else 0,
+                                                   C.c_void_p(int(dev_ptr)), int(nbytes), 0, int(simulation)), 'ppn_read_observation')
+
+    def observation_length(self, layout='full'):
+        return int(self._lib.ppn_observation_length(self._h, self.OBS_LAYOUTS[layout]))
 
     def write(self, name, values):
         fid = _lib.FIELD_ID[name]

@@ -161,3 +161,86 @@ def test_gpu_intermediate_busbar_capacities(cap, solver):
     2-word kernels with spare busbars (128), against the oracle under random node splitting; no environment may hit the capacity flag."""
     st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 20, 48, solver, seed=77, max_active_buses=cap)
     assert st['split_buses'] > 0
+
+
+class _DLPackOnly(object):
+    """A device array that is not a torch tensor: only the DLPack protocol (what cupy / jax arrays offer)."""
+
+    def __init__(self, t):
+        self._t = t
+
+    def __dlpack__(self, stream=None):
+        return self._t.__dlpack__()
+
+    def __dlpack_device__(self):
+        return self._t.__dlpack_device__()
+
+
+def test_gpu_batched_tensor_api():
+    """BatchedRunEnv.step / search take device tensors (torch CUDA, or anything with __dlpack__) and answer with
+    device tensors -- no PCIe crossing; same numbers as the host-array path."""
+    import os
+    import torch
+    from helpers import ENVS
+    from pypownet_amd.batched import BatchedRunEnv
+    envdir = os.path.join(ENVS, 'default14')
+    B = 64
+    host = BatchedRunEnv(envdir, 'level0', B, device=0, config_overrides={'solver': 'newton'})
+    dev = BatchedRunEnv(envdir, 'level0', B, device=0, config_overrides={'solver': 'newton'})
+    host.reset()
+    dev.reset()
+    rng = np.random.default_rng(0)
+    case = host.case
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    for t in range(12):
+        a = ec.random_actions(case, rng, B)
+        ta = torch.from_numpy(a).cuda()
+        o1, d1, f1, i1 = host.step(a, auto_reset=True)
+        o2, d2, f2, i2 = dev.step(ta if t % 2 else _DLPackOnly(ta), auto_reset=True)
+        assert o2.is_cuda and d2.is_cuda and o2.dtype == torch.float64
+        assert np.array_equal(o1, o2.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(d1, d2.cpu().numpy()) and np.array_equal(f1, f2.cpu().numpy()) and np.array_equal(i1, i2.cpu().numpy())
+        o3 = dev.step(torch.zeros_like(ta), auto_reset=True, layout='minimalist', obs_dtype=np.float32)[0]
+        host.step(np.zeros_like(a), auto_reset=True)
+        assert o3.dtype == torch.float32 and o3.shape[1] == dev.engine.observation_length('minimalist')
+    K = 5
+    cand = np.stack([ec.random_actions(case, rng, B) for _ in range(K)], axis=1)
+    r1, d1, f1, o1 = host.search(cand, want_obs=True)
+    r2, d2, f2, o2 = dev.search(torch.from_numpy(cand).cuda(), want_obs=True)
+    assert r2.is_cuda and np.array_equal(f1, f2.cpu().numpy()) and np.array_equal(d1, d2.cpu().numpy())
+    np.testing.assert_allclose(r1, r2.cpu().numpy(), rtol=1e-13, atol=1e-13)      # (sums of the 5 components in another order)
+    assert np.array_equal(o1, o2.cpu().numpy(), equal_nan=True)
+
+
+@pytest.mark.parametrize('single_controller', [False, True])
+def test_gpu_bench_two_ranks_share_one_gpu(single_controller, tmp_path):
+    """The N > 1 path of bench.py end to end: two ranks (PPN_BENCH_BACKEND=gloo lets them share this box's one GPU; on the
+    8-GPU node the driver uses RCCL), launched the way the driver launches it.  Rank r must play environments [r B, (r+1) B) of
+    the global assignment, the line must carry the aggregate of both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import zlib
+    from helpers import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    B = 256
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', str(B),
+           '--no-cpu-baseline'] + (['--single-controller'] if single_controller else [])
+    env = dict(os.environ, PPN_BENCH_BACKEND='gloo')
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['value'] > 0 and d['scaling'] == 'weak'
+    case, conf, chronics = bench.load_workload()
+    want = []
+    for r in range(2):
+        slots, t0 = bench.env_assignment(r * B, B, chronics)
+        want.append(zlib.crc32(slots.tobytes() + t0.tobytes()))
+    assert d['config']['env_assignment_crc32'] == want
+    # the aggregate: both ranks' environments over the slowest rank's time
+    assert abs(d['value'] - 2 * B * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']

@@ -46,3 +46,13 @@ if __name__ == '__main__':
                            % [c.name for c in chronics], 'n_samples': int(A.shape[0]),
                    'limits_a': [float(v) for v in lim]}, f)
     print('wrote', out, 'min/max', lim.min(), lim.max())
+    # SURVEY.md 8d "config 3" as written: limit_k = max(50, 1.10 x I_k(base case at t = 0)) rounded to integer A -- the second
+    # headline variant bench.py reports (cascade-heavier, fewer game overs)
+    base = rows[0]                       # first timestep of the first chronic, every line in service
+    lim110 = np.maximum(50.0, np.round(1.10 * base))
+    out = os.path.join(ROOT, 'tests', 'golden', 'envs', 'default118', 'bench_limits_110.json')
+    with open(out, 'w') as f:
+        json.dump({'rule': 'max(50, round(1.10 x I_k(t = 0))) with I_k(t = 0) the ampere flows of the first timestep of chronic %s, '
+                           'every line in service (SURVEY.md 8d config 3)' % chronics[0].name,
+                   'limits_a': [float(v) for v in lim110]}, f)
+    print('wrote', out, 'min/max', lim110.min(), lim110.max())

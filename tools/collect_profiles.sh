@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel statistics, HBM / SQ counters (separate --pmc passes, as the
 # MI355X guide prescribes), the per-phase cycle profile and the bench line of the current build.  Output: gpurun_out/<tag>/
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- $BENCH > /dev/null 2>&1
@@ -15,8 +15,8 @@ cd $ROOT
 python tools/profile_phases.py 4096 10 > $OUT/phase_profile_b4096.txt 2>&1
 python tools/profile_phases.py 32768 4 > $OUT/phase_profile_b32768.txt 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-PPN_LAUNCH_ORDER=0 python bench.py --no-cpu-baseline > $OUT/bench_no_launch_order.json 2>/dev/null
-python bench.py --batch 32768 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_b32768.json 2>/dev/null
+PPN_LAUNCH_ORDER=0 python bench.py --no-cpu-baseline --no-other-configs > $OUT/bench_no_launch_order.json 2>/dev/null
+python bench.py --batch 32768 --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/bench_b32768.json 2>/dev/null
 tail -1 $OUT/bench.json | cut -c1-400
 ls $OUT $OUT/stats | head -30
 # afterwards, in the development container: python tools/summarize_pmc.py $TAG  (-> profiles/)
