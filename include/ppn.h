@@ -266,7 +266,9 @@ int32_t ppn_dim(const ppn_engine* e, int32_t which);   /* 0 nS, 1 nP, 2 nL, 3 nl
                                                           6 batch, 7 lds_bytes, 8 max_active_buses,
                                                           9 lu_capacity, 10 n_chronic_slots, 11 base LU fill,
                                                           12-14 capacities of the elimination schedule (filled 2x2
-                                                          block entries, Schur pair records, triple records) */
+                                                          block entries, Schur pair records, triple records), 15 Q-plane
+                                                          capacity of the Newton storage, 16 environments resident per CU
+                                                          (hipOccupancyMaxActiveBlocksPerMultiprocessor of the step kernel) */
 const char* ppn_version(void);
 
 #ifdef __cplusplus

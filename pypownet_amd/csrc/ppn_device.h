@@ -25,6 +25,7 @@ struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LD
 #define WSYNC() ((void)0)
 #define WSYNC_G() ((void)0)
 // per-lane variables that live across LANE_LOOP regions (registers on the GPU)
+#define PPN_OPAQUE_S(x) (x)
 #define LANE_VAR(type, name) type name[64]
 #define LANE_ARR(type, name, n) type name[64][n]
 #define LV(name) name[lane]
@@ -40,6 +41,11 @@ static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 //  loop invariants of the episode / cascade / Newton loops, and hoisted out of them they would sit in VGPRs for the whole
 //  kernel -- hundreds of them; recomputing them per phase costs a few VALU instructions)
 __device__ __forceinline__ int ppn_opaque_lane(int x) { __asm__ volatile("" : "+v"(x)); return x; }
+// (the same for the environment index, in a scalar register: a function that re-derives its environment's row pointers from an
+//  opaque copy keeps them alive only for its own duration -- derived once at kernel entry they are ~70 scalar registers that
+//  live, i.e. are spilled and reloaded, across every phase of the kernel)
+__device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" : "+s"(x)); return x; }
+#define PPN_OPAQUE_S(x) ppn_opaque_uniform(x)
 #define LANE_LOOP for (int lane = ppn_opaque_lane(lane0), once_ = 1; once_; once_ = 0)
 // One wavefront per workgroup: the LDS unit executes the DS instructions of a wave in issue order (a ds_read issued
 // after a ds_write / ds_add of any lane of the same wave observes it), so ordering LDS phases only needs the COMPILER
@@ -191,20 +197,21 @@ struct DevState {
 // the byte offset that turns entry index e of a row-i entry into its Q half ((char*)lu + qrel[i] + 16 e), 0xFFFF = no Q row.
 struct Smem {
   // across the step
-  u8 *st, *on, *en, *pn, *ln, *over, *subchg, *touched;
-  double* amps;
+  u8 *st, *on, *en, *pn, *ln, *touched;
+  u8 *over, *subchg;                  // between solves only: they share the bytes of lf / lt (which live inside a solve only)
+  double* amps;                       // ampere flows of the last solve: at the head of region R (dead from the solve's outputs to the next solve's setup)
   // across a solve
-  u8 *row2int, *r2s, *nv, *lf, *lt;   // r2s: bus row -> schedule index (superset), row2int: live buses only
-  u16 *int2row, *ediag, *qrel;
+  u8 *r2s, *nv, *lf, *lt;             // r2s: bus row -> schedule index (every busbar of the schedule; the live ones are those with touched[row])
+  u16 *qrel;
   double *vc, *ivm, *rhs, *zero;      // vc: V = vc[2i] + j vc[2i+1]; ivm: 1 / |V_i|; zero: {0, 0, 0, 1} = the halves a missing Q row reads as
   // region R
   double* lu;
   double *vm, *va, *psp, *qsp, *mr, *mi;      // bus vectors (view of R)
   u64 *adj0;                                   // setup scratch of a solve (view of R)
-  double *yre, *yim, *gvg;
+  double *yre, *yim;
   u8 *hasgen, *genon;
   u64* adjF;                                   // schedule_build scratch (view of R, with adj0)
-  u16 *yptr, *scn, *moffq, *toffq, *rowptr, *lvlp, *lvlm, *lvlt;
+  u16 *yptr, *scn, *moffq, *toffq, *rowptr, *lvlp, *lvlm, *lvlt, *int2row, *ediag;
   u8 *pvl, *kq, *mem, *mown;
   // compact carve only (is_action_valid)
   u8* act;
@@ -239,24 +246,27 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
     return o;
   }
   PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
-  PPN_TAKE(over, u8, nl) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(touched, u8, nrows) PPN_TAKE(amps, double, nl * 8)
-  PPN_TAKE(row2int, u8, nrows) PPN_TAKE(r2s, u8, nrows) PPN_TAKE(nv, u8, NB) PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl)
-  PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(ediag, u16, NB * 2) PPN_TAKE(qrel, u16, NB * 2)
+  PPN_TAKE(touched, u8, nrows)
+  PPN_TAKE(r2s, u8, nrows) PPN_TAKE(nv, u8, NB)
+  { const size_t lb = (nl > (size_t)d.nS ? nl : (size_t)d.nS); PPN_TAKE(lf, u8, lb) PPN_TAKE(lt, u8, lb) }
+  S.over = S.lf; S.subchg = S.lt;
+  PPN_TAKE(qrel, u16, NB * 2)
   PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(ivm, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
   const size_t r0 = o;
   S.lu = (double*)(base + r0);
+  S.amps = (double*)(base + r0);
   // view: schedule_build scratch
   PPN_TAKE(adj0, u64, NB * W * 8)
   const size_t after_adj0 = o;
   PPN_TAKE(adjF, u64, NB * W * 8)
   PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(scn, u16, (nrows + 1) * 2) PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)
   PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
-  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2)
+  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(ediag, u16, NB * 2)
   PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
   const size_t build_end = o;
   // view: setup scratch of a solve (adj0 shared with the view above), then the bus vectors
   o = after_adj0;
-  PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8) PPN_TAKE(gvg, double, NB * 8)
+  PPN_TAKE(yre, double, (size_t)d.YCAP * 8) PPN_TAKE(yim, double, (size_t)d.YCAP * 8)
   PPN_TAKE(hasgen, u8, NB) PPN_TAKE(genon, u8, NB)
   const size_t fd_lu_end = r0 + (size_t)d.ECAP * 16;      // B' and B'' as scalar matrices: 2 x ECAP doubles
   if (!NT && o < fd_lu_end) o = fd_lu_end;               // (fast-decoupled / DC: the vectors sit beside the factors)
@@ -267,6 +277,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   o = build_end;
   if (vec_end > o) o = vec_end;
   if (lu_end > o) o = lu_end;
+  if (r0 + nl * 8 > o) o = r0 + nl * 8;
 #undef PPN_TAKE
   return (o + 15) & ~(size_t)15;
 }

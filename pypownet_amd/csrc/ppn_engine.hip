@@ -383,9 +383,27 @@ extern "C" size_t ppn_field_bytes(const ppn_engine* e, ppn_field f) {
   return fi.elem * fi.n;
 }
 
+#ifndef PPN_EMU
+template <int W>
+static int step_kernel_occupancy(const ppn_engine* e) {
+  int n = 0;
+  hipError_t rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 1>, 64, e->lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 0>, 64, e->lds_bytes);
+  return rc == hipSuccess ? n : -1;
+}
+#endif
+
 extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
   if (!e) return -1;
   const DevCase& d = e->dc;
+  if (which == 16) {      // environments (workgroups of the step kernel) resident per CU, as the runtime computes it
+#ifdef PPN_EMU
+    return 1;
+#else
+    enter(e);
+    return e->W == 1 ? step_kernel_occupancy<1>(e) : (e->W == 2 ? step_kernel_occupancy<2>(e) : step_kernel_occupancy<4>(e));
+#endif
+  }
   switch (which) {
     case 0: return d.nS; case 1: return d.nP; case 2: return d.nL; case 3: return d.nl;
     case 4: return d.alen; case 5: return d.obslen; case 6: return e->batch; case 7: return (int32_t)e->lds_bytes;

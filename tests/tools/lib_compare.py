@@ -36,19 +36,19 @@ def main():
         act = torch.zeros((batch, case.action_length), dtype=torch.uint8, device='cuda')
         torch.cuda.synchronize()
         for _ in range(5):
-            eng.step_device(act.data_ptr(), auto_reset=True)
+            eng.step_device(act.data_ptr(), auto_reset=2)
         eng.sync()
         eng.kernel_time(reset=True)
         s0, i0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
         t = time.perf_counter()
         for _ in range(steps):
-            eng.step_device(act.data_ptr(), auto_reset=True)
+            eng.step_device(act.data_ptr(), auto_reset=2)
         eng.sync()
         el = time.perf_counter() - t
         kms, kn = eng.kernel_time(reset=True)
         s1, i1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
         print(json.dumps({'lib': lib, 'env': envname, 'solver': solver, 'batch': batch, 'env_steps_per_s': batch * steps / el,
-                          'step_kernel_ms': kms / max(kn, 1), 'lds_bytes_per_env': eng.lds_bytes,
+                          'step_kernel_ms': kms / max(kn, 1), 'lds_bytes_per_env': eng.lds_bytes, 'envs_per_cu': eng.dim(16),
                           'solves_per_step': float(s1 - s0) / (batch * steps),
                           'iters_per_solve': float(i1 - i0) / max(float(s1 - s0), 1.0),
                           'checksum_vm': float(np.nansum(eng.read('VM')))}), flush=True)

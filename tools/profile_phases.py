@@ -64,6 +64,8 @@ def main():
         print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
     for k, name in ((16, 'LU level bounds + record prefetch'), (17, 'LU phase 0 (invert, y\')'), (18, 'LU phase 1 (U\', forward)'), (19, 'LU phase 2 (Schur)')):
         print('%-28s total %.3e cyc  %8.0f cyc per iteration' % (name, tot[k], tot[k] / nit))
+    for k, name in ((20, 'evaluation pass 0 (V, clears)'), (21, 'evaluation pass 1 (Ybus entries)'), (22, 'evaluation pass 2 (buses, norm)')):
+        print('%-28s total %.3e cyc  %8.0f cyc per evaluation (iterations + solves)' % (name, tot[k], tot[k] / (nit + nsolve)))
     # whole kernel body per environment: shader cycles (clock64) and 100 MHz wall ticks (wall_clock64)
     kt = eng.kernel_time()
     body_c, body_w = tot[14], tot[15] * 1e-8
