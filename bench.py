@@ -61,7 +61,7 @@ def measured_traffic(batch):
     by tools/collect_profiles.sh, summary committed under profiles/); None when no summary matches this batch size --
     counters cannot be collected from inside the timed run."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')) as f:
             p = json.load(f)
         return float(p['hbm_bytes_per_launch']) if int(p['batch']) == int(batch) else None
     except Exception:

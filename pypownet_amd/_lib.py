@@ -2,6 +2,7 @@
 importing the engine without the built extension raises, loudly."""
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libppn.so')
@@ -76,6 +77,14 @@ EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limit
 
 def load_library():
     """Loads pypownet_amd/libppn.so -- the one and only library of the product path -- and declares its signatures."""
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  One process must not end up with two: whichever libamdhip64 is
+    # loaded first serves both, and a torch that initialises its device AFTER libppn.so brought in the system runtime finds
+    # "No HIP GPUs".  So when torch is installed it is imported (not initialised) before the engine library.
+    if 'torch' not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'pypownet_amd: the HIP extension %s is missing. Build it with `python __graft_entry__.py` '

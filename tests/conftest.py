@@ -18,3 +18,16 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def envs_dir():
     return ENVS
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _one_hip_runtime():
+    """PyTorch-ROCm bundles its own HIP runtime: it has to be the first one loaded in the process (pypownet_amd/_lib.py does the
+    same for the product library; the test harness loads other libraries itself)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield
