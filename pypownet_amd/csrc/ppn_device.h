@@ -245,11 +245,16 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
     PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
     return o;
   }
-  PPN_TAKE(st, u8, nl) PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
-  PPN_TAKE(touched, u8, nrows)
-  PPN_TAKE(r2s, u8, nrows) PPN_TAKE(nv, u8, NB)
-  { const size_t lb = (nl > (size_t)d.nS ? nl : (size_t)d.nS); PPN_TAKE(lf, u8, lb) PPN_TAKE(lt, u8, lb) }
-  S.over = S.lf; S.subchg = S.lt;
+  // (LDS is handed out in granules of 1280 bytes -- 128 per CU: seven environments per CU need 18 granules or fewer each, 23040
+  //  bytes -- so the byte arrays are packed back to back, only the group is aligned)
+#define PPN_TAKE8(field, bytes) S.field = (u8*)(base + o); o += (size_t)(bytes);
+  PPN_TAKE8(st, nl) PPN_TAKE8(on, nl) PPN_TAKE8(en, nl) PPN_TAKE8(pn, (size_t)d.nP) PPN_TAKE8(ln, (size_t)d.nL)
+  PPN_TAKE8(touched, nrows) PPN_TAKE8(r2s, nrows) PPN_TAKE8(nv, NB)
+  // line-end tables (schedule index of a line's two busbars): the fast-decoupled / DC kernels use them until their output pass;
+  // the Newton kernels only up to the connectivity sweep, so theirs sit in region R (behind the adjacency bitsets)
+  const size_t lb = (nl > (size_t)d.nS ? nl : (size_t)d.nS);
+  if (!NT) { PPN_TAKE8(lf, lb) PPN_TAKE8(lt, lb) }
+  o = (o + 15) & ~(size_t)15;
   PPN_TAKE(qrel, u16, NB * 2)
   PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(ivm, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
   const size_t r0 = o;
@@ -257,6 +262,9 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   S.amps = (double*)(base + r0);
   // view: schedule_build scratch
   PPN_TAKE(adj0, u64, NB * W * 8)
+  if (NT) { PPN_TAKE8(lf, lb) PPN_TAKE8(lt, lb) o = (o + 15) & ~(size_t)15; }
+#undef PPN_TAKE8
+  S.over = S.lf; S.subchg = S.lt;      // between solves only (cascade flags, per-substation action flags): they share the bytes of lf / lt
   const size_t after_adj0 = o;
   PPN_TAKE(adjF, u64, NB * W * 8)
   PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(scn, u16, (nrows + 1) * 2) PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)

@@ -599,7 +599,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     // 1.15x + 1.0x per doubling (2.15x with every busbar active), rules.lu_capacity overrides it
     ecap = (NB > nS) ? (int)(pairs * (1.15 + 1.0 * extra)) + 16 : pairs;
   }
-  d.ECAP = (ecap + 7) & ~7;
+  d.ECAP = (NB > nS) ? ((ecap + 7) & ~7) : ecap;      // (exact without spare busbars: every 16 bytes count towards the LDS granule)
   d.QCAP = d.ECAP;
   d.LUCAP = 2 * (d.ECAP + d.QCAP);
   e->auto_qcap = !(r->lu_capacity > 0);
@@ -746,11 +746,12 @@ static int size_q_plane(ppn_engine* e) {
   if (d.NB == nS) qcap = (int)worst;
   else qcap = (int)(((double)worst / e->pattern_pairs + 0.12) * d.ECAP) + 8;
   if (getenv("PPN_QCAP_FULL")) qcap = d.ECAP;
-  qcap = std::min(d.ECAP, (qcap + 7) & ~7);
+  qcap = std::min(d.ECAP, d.NB == nS ? qcap : ((qcap + 7) & ~7));
   d.QCAP = qcap;
   d.LUCAP = 2 * (d.ECAP + d.QCAP);
   Smem tmp;
   e->lds_bytes = ppn_carve(d, e->W, 1, nullptr, &tmp);
+  { const char* v = getenv("PPN_LDS_PAD"); if (v) e->lds_bytes += (size_t)atoi(v); }      // (occupancy experiments: fewer environments per CU)
 #ifndef PPN_EMU
   int rc_attr = 0;
   switch (e->W) { case 1: rc_attr = set_lds_attr<1>(e->lds_bytes); break; case 2: rc_attr = set_lds_attr<2>(e->lds_bytes); break;
