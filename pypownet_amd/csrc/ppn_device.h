@@ -250,10 +250,10 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
 #define PPN_TAKE8(field, bytes) S.field = (u8*)(base + o); o += (size_t)(bytes);
   PPN_TAKE8(st, nl) PPN_TAKE8(on, nl) PPN_TAKE8(en, nl) PPN_TAKE8(pn, (size_t)d.nP) PPN_TAKE8(ln, (size_t)d.nL)
   PPN_TAKE8(touched, nrows) PPN_TAKE8(r2s, nrows) PPN_TAKE8(nv, NB)
-  // line-end tables (schedule index of a line's two busbars): the fast-decoupled / DC kernels use them until their output pass;
-  // the Newton kernels only up to the connectivity sweep, so theirs sit in region R (behind the adjacency bitsets)
+  // line-end tables (schedule index of a line's two busbars).  (Moving the Newton kernels' copies into region R -- they only
+  // need them up to the connectivity sweep -- broke the 4-word kernels on the GPU and stays out.)
   const size_t lb = (nl > (size_t)d.nS ? nl : (size_t)d.nS);
-  if (!NT) { PPN_TAKE8(lf, lb) PPN_TAKE8(lt, lb) }
+  { PPN_TAKE8(lf, lb) PPN_TAKE8(lt, lb) }
   o = (o + 15) & ~(size_t)15;
   PPN_TAKE(qrel, u16, NB * 2)
   PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(ivm, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
@@ -262,7 +262,6 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   S.amps = (double*)(base + r0);
   // view: schedule_build scratch
   PPN_TAKE(adj0, u64, NB * W * 8)
-  if (NT) { PPN_TAKE8(lf, lb) PPN_TAKE8(lt, lb) o = (o + 15) & ~(size_t)15; }
 #undef PPN_TAKE8
   S.over = S.lf; S.subchg = S.lt;      // between solves only (cascade flags, per-substation action flags): they share the bytes of lf / lt
   const size_t after_adj0 = o;
