@@ -69,8 +69,14 @@ __device__ __forceinline__ double ppn_readlane_d(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 #define PPN_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#ifdef PPN_MARKS      // developer aid (tools/dev): named comment lines in the ISA listing
+#define PPN_MARK(s) __asm__ volatile("; MARK " s ::: "memory")
+#endif
 __device__ __forceinline__ int ppn_popc(u64 x) { return __popcll(x); }
 __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
+#endif
+#ifndef PPN_MARK
+#define PPN_MARK(s) ((void)0)
 #endif
 
 // phase profiling (tools/profile_phases.py builds a separate libppn_prof.so with -DPPN_PROF)
