@@ -26,6 +26,7 @@ struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LD
 #define WSYNC_G() ((void)0)
 // per-lane variables that live across LANE_LOOP regions (registers on the GPU)
 #define PPN_OPAQUE_S(x) (x)
+#define PPN_OPAQUE_V(x) (x)
 #define LANE_VAR(type, name) type name[64]
 #define LANE_ARR(type, name, n) type name[64][n]
 #define LV(name) name[lane]
@@ -46,6 +47,9 @@ __device__ __forceinline__ int ppn_opaque_lane(int x) { __asm__ volatile("" : "+
 //  live, i.e. are spilled and reloaded, across every phase of the kernel)
 __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" : "+s"(x)); return x; }
 #define PPN_OPAQUE_S(x) ppn_opaque_uniform(x)
+// (and for a per-lane value whose derived quantities must be recomputed where they are used instead of being hoisted out of
+//  the Newton loop into registers -- or spilled scalar pairs -- of their own)
+#define PPN_OPAQUE_V(x) ((unsigned)ppn_opaque_lane((int)(x)))
 #define LANE_LOOP for (int lane = ppn_opaque_lane(lane0), once_ = 1; once_; once_ = 0)
 // One wavefront per workgroup: the LDS unit executes the DS instructions of a wave in issue order (a ds_read issued
 // after a ds_write / ds_add of any lane of the same wave observes it), so ordering LDS phases only needs the COMPILER
@@ -78,6 +82,27 @@ __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #ifndef PPN_MARK
 #define PPN_MARK(s) ((void)0)
 #endif
+// Bounded per-lane global loads without a branch: the index is clamped into the array (cnt >= 1) and the load is
+// unconditional -- scalar base + 32-bit lane offset.  A guarded load (`i < n ? p[i] : 0`) is compiled as an exec-mask save /
+// branch / restore around 64-bit address arithmetic, per fetch; the step prologue and the setup of a solve hold dozens.
+// ppn_ldc: lanes past the end get the last element (for consumers that are guarded themselves); ppn_ldz: they get 0.
+template <class T> PPN_DEV T ppn_ldc(const T* p, int idx, int cnt) {
+  return *(const T*)((const char*)p + (size_t)((unsigned)(idx < cnt ? idx : cnt - 1) * (unsigned)sizeof(T)));
+}
+template <class T> PPN_DEV T ppn_ldz(const T* p, int idx, int cnt) {
+  const T v = ppn_ldc(p, idx, cnt);
+  return idx < cnt ? v : (T)0;
+}
+// x if bit `bit` of m is set, else +0.0 -- as an AND with a sign-extended bit field (v_bfe_i32 + 2 v_and_b32): no condition
+// register, nothing for the compiler to keep in (spilled) scalar pairs across the iterations
+PPN_DEV double ppn_keep_if_bit(double x, unsigned m, int bit) {
+  const u64 k = (u64)(long long)(-(int)((m >> bit) & 1u));
+  u64 b;
+  __builtin_memcpy(&b, &x, 8);
+  b &= k;
+  __builtin_memcpy(&x, &b, 8);
+  return x;
+}
 
 // phase profiling (tools/profile_phases.py builds a separate libppn_prof.so with -DPPN_PROF)
 #if defined(PPN_PROF) && !defined(PPN_EMU)
@@ -87,7 +112,11 @@ __device__ __forceinline__ int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
 #define PROF_BODY_END(E_) do { if (lane0 == 0) { (E_).prof[14] += clock64() - pb_c_; (E_).prof[15] += wall_clock64() - pb_w_; } } while (0)
 #else
 #define PROF_BEGIN() ((void)0)
+#ifdef PPN_MARKS
+#define PROF_MARK(E_, id) __asm__ volatile("; MARK prof_" #id ::: "memory")
+#else
 #define PROF_MARK(E_, id) ((void)0)
+#endif
 #define PROF_BODY_BEGIN() ((void)0)
 #define PROF_BODY_END(E_) ((void)0)
 #endif

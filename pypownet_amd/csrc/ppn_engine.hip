@@ -418,6 +418,8 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (!c || !r || !out || batch <= 0) return fail(nullptr, PPN_E_INVALID, "ppn_create: null argument or batch <= 0");
   if (c->n_bus_rows <= 0 || (c->n_bus_rows & 1) || c->bus_cols < 10 || c->gen_cols < 8 || c->branch_cols < 11)
     return fail(nullptr, PPN_E_INVALID, "ppn_create: case arrays have unexpected shapes");
+  if (c->n_gen <= 0 || c->n_branch <= 0)
+    return fail(nullptr, PPN_E_INVALID, "ppn_create: a case needs at least one production and one line");
   ppn_engine* e = new ppn_engine();
   e->batch = batch; e->device = device; e->rules = *r;
 #ifndef PPN_EMU
@@ -453,6 +455,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   }
   if (slack_row < 0) return bad("case has no slack bus (type 3)");
   const int nL = (int)loads.size();
+  if (nL <= 0) return bad("a case needs at least one load");
   std::vector<int> gen_sub(nP), load_sub(nL), or_sub(nl), ex_sub(nl), sub_load(nS, -1), sub_gen(nS, -1);
   std::vector<double> qmax(nP), qmin(nP), qg0(nP);
   for (int g = 0; g < nP; ++g) {
