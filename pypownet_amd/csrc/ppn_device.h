@@ -160,6 +160,8 @@ struct DevCase {
   int QCAP;                    // capacity of the Q plane of the Newton storage: pattern entries in rows of PQ buses (<= ECAP)
   double baseMVA;
   const double *bus_gs, *bus_bs, *bus_kv, *vm0, *va0;   // [nrows]  (va0 degrees)
+  const double* gen_kv;                                 // [2 nP] baseKV of the bus row a production sits on: busbar 0, busbar 1
+  const double* line_kv;                                // [2 nl] baseKV of the bus row at a line's origin: busbar 0, busbar 1
   const int *gen_sub, *load_sub, *or_sub, *ex_sub;       // substation index of each element
   const int *sub_load;                                   // [nS] load index at substation or -1
   const double *gen_qmax, *gen_qmin, *gen_qg0;           // [nP]  (qg0: case value of gen[:,QG])

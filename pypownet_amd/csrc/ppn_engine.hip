@@ -627,6 +627,14 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     d.cache_stride = (int)o;
   }
   d.bus_gs = upload(e, gs, e->allocs); d.bus_bs = upload(e, bs, e->allocs); d.bus_kv = upload(e, kv, e->allocs);
+  {
+    std::vector<double> gkv((size_t)2 * nP);
+    for (int node = 0; node < 2; ++node) for (int g = 0; g < nP; ++g) gkv[(size_t)node * nP + g] = kv[gen_sub[g] + node * nS];
+    d.gen_kv = upload(e, gkv, e->allocs);
+    std::vector<double> lkv((size_t)2 * nl);
+    for (int node = 0; node < 2; ++node) for (int l = 0; l < nl; ++l) lkv[(size_t)node * nl + l] = kv[or_sub[l] + node * nS];
+    d.line_kv = upload(e, lkv, e->allocs);
+  }
   d.vm0 = upload(e, vm0, e->allocs); d.va0 = upload(e, va0, e->allocs);
   d.gen_sub = upload(e, gen_sub, e->allocs); d.load_sub = upload(e, load_sub, e->allocs);
   d.or_sub = upload(e, or_sub, e->allocs); d.ex_sub = upload(e, ex_sub, e->allocs);
