@@ -164,7 +164,7 @@ def random_node_splitting(case, rng, batch):
 
 
 def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=None, split=False, max_active=None, warmup=4,
-                histogram=False):
+                histogram=False, lu_capacity=0, watch_capacity=0):
     """One of the other single-GPU configurations of BASELINE.json, timed like the headline (device-resident actions, K steps
     between synchronisations, step-kernel time from HIP events) and priced with its own SURVEY.md 8d byte count."""
     import torch
@@ -173,6 +173,8 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
     kw = {}
     if max_active:
         kw['max_active_buses'] = max_active
+    if lu_capacity:
+        kw['lu_capacity'] = lu_capacity
     eng = Engine(case, conf, batch, device=device, chronics=chronics, thermal_limits=limits, **kw)
     slots, t0 = env_assignment(0, batch, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
@@ -208,6 +210,13 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
            'engine_capacity_flags_last_step': int((eng.read('FLAG') == 4).sum())}
     if split:
         out['illegal_fraction_last_step'] = float((eng.read('ILLEGAL') != 0).mean())
+    if watch_capacity:     # untimed: the capacity flag of every environment looked at after every one of some more steps
+        raised = 0
+        for k in range(watch_capacity):
+            eng.step_device(acts[k % n_act].data_ptr(), auto_reset=auto_reset)
+            raised += int((eng.read('FLAG') == 4).sum())
+        out['lu_capacity'] = lu_capacity
+        out['engine_capacity_flags_in_%d_watched_steps' % watch_capacity] = raised
     if histogram:
         out['note'] = 'DONE / CASCADE_DEPTH read back every step for the statistics: the rate includes that synchronisation'
         out['game_over_rate'] = n_done / float(batch * steps)
@@ -238,6 +247,13 @@ def other_configs(device, auto_reset, steps):
     add('configs[4] share of one GPU: default118 AC Newton-Raphson, random node splitting every step, batch 1024, every busbar may '
         'be active (W = 4 kernels, schedule rebuilt on every accepted switch)', ENV_NAME, 'newton', 1024, steps, device, auto_reset,
         limits=lim, split=True)
+    # matrix capacity 1.5 x the base pattern instead of the default 2.15 x (tools/fill_survey.py: the largest pattern over 10^6 random
+    # topologies is 1.39 x): the working set drops under 40,960 bytes = 32 LDS granules, four environments per CU instead of three
+    add('configs[4] share of one GPU with rules.lu_capacity = 3976 (pattern capacity 1.5 x base: 4 environments per CU), batch 1024',
+        ENV_NAME, 'newton', 1024, steps, device, auto_reset, limits=lim, split=True, lu_capacity=3976, watch_capacity=20)
+    add('configs[4] workload at a batch that fills the GPU: random node splitting every step, batch 8192 (the whole of configs[4] on '
+        'one GPU), rules.lu_capacity = 3976', ENV_NAME, 'newton', 8192, max(8, steps // 3), device, auto_reset, limits=lim, split=True,
+        lu_capacity=3976, watch_capacity=20)
     add('configs[2] with the limit rule of SURVEY.md 8d config 3: limit = max(50, 1.10 x I(t = 0))', ENV_NAME, 'newton', 4096, steps,
         device, auto_reset, limits=limits_110(case118), max_active=case118.nS, histogram=True)
     return out

@@ -104,7 +104,7 @@ typedef struct ppn_rules {
    * attached in any one topology (at least the number of substations; at most 254) and sizes the LDS working set; a
    * topology that exceeds a capacity reports PPN_FLAG_ENGINE_CAPACITY for that environment. */
   int32_t max_active_buses;
-  int32_t lu_capacity;                /* doubles of LU storage per environment, 0 = auto */
+  int32_t lu_capacity;                /* capacity of the filled pattern, as doubles of uniform 2 x 2 blocks (4 per entry), 0 = auto */
   int32_t rng_seed;                   /* PPN_LOOP_RANDOM: seed of the per-environment chronic draws */
 } ppn_rules;
 

@@ -605,7 +605,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.ECAP = (NB > nS) ? ((ecap + 7) & ~7) : ecap;      // (exact without spare busbars: every 16 bytes count towards the LDS granule)
   d.QCAP = d.ECAP;
   d.LUCAP = 2 * (d.ECAP + d.QCAP);
-  e->auto_qcap = !(r->lu_capacity > 0);
+  e->auto_qcap = true;      // (rules.lu_capacity sizes the P plane; the Q plane always follows the chronics: size_q_plane)
   e->pattern_pairs = pairs;
   e->sub_gen_ = sub_gen;
   {

@@ -163,6 +163,14 @@ def test_gpu_intermediate_busbar_capacities(cap, solver):
     assert st['split_buses'] > 0
 
 
+def test_gpu_tuned_pattern_capacity():
+    """rules.lu_capacity = 3976 (pattern capacity 1.5 x the base pattern, every busbar may be active): the working set of the
+    4-word kernels drops to 32 LDS granules -- four environments per CU, the configuration of bench.py's configs[4] lines -- and
+    the results stay those of the oracle under random node splitting; no environment may hit the capacity flag."""
+    st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 20, 48, 'newton', seed=78, lu_capacity=3976)
+    assert st['split_buses'] > 0
+
+
 class _DLPackOnly(object):
     """A device array that is not a torch tensor: only the DLPack protocol (what cupy / jax arrays offer)."""
 
