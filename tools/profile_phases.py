@@ -66,6 +66,11 @@ def main():
         print('%-28s total %.3e cyc  %8.0f cyc per iteration' % (name, tot[k], tot[k] / nit))
     for k, name in ((20, 'evaluation pass 0 (V, clears)'), (21, 'evaluation pass 1 (Ybus entries)'), (22, 'evaluation pass 2 (buses, norm)')):
         print('%-28s total %.3e cyc  %8.0f cyc per evaluation (iterations + solves)' % (name, tot[k], tot[k] / (nit + nsolve)))
+    if split:
+        for k, name in ((23, 'numbering, line ends'), (24, 'pivots per level'), (25, 'adjacency, Ybus row pointers'), (26, 'symbolic elimination'),
+                        (27, 'entry numbering, pivot records, line / Ybus entry tables'), (28, 'fill-in list, pair / triple records'),
+                        (29, 'level table, dense-tail map, header')):
+            print('schedule_build: %-58s total %.3e cyc  %5.1f %% of the rebuilds  %8.0f cyc per env-step' % (name, tot[k], 100.0 * tot[k] / max(tot[23:30].sum(), 1.0), tot[k] / float(B * steps)))
     # whole kernel body per environment: shader cycles (clock64) and 100 MHz wall ticks (wall_clock64)
     kt = eng.kernel_time()
     body_c, body_w = tot[14], tot[15] * 1e-8
