@@ -414,6 +414,7 @@ extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
 }
 
 static void default_reward(double* rw, double c);
+static int rebalance_base_triples(ppn_engine* e);
 extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, int32_t device, ppn_engine** out) {
   if (!c || !r || !out || batch <= 0) return fail(nullptr, PPN_E_INVALID, "ppn_create: null argument or batch <= 0");
   if (c->n_bus_rows <= 0 || (c->n_bus_rows & 1) || c->bus_cols < 10 || c->gen_cols < 8 || c->branch_cols < 11)
@@ -886,12 +887,92 @@ extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const
       rcc |= dev_d2h(hdr, e->base_cache, sizeof hdr, e->stream);
       if (rcc) return fail(e, PPN_E_HIP, "ppn_reset: shared schedule copy failed: %s", dev_err());
       if (hdr[0] == 1) {
+        if (rebalance_base_triples(e)) return fail(e, PPN_E_HIP, "ppn_reset: shared schedule update failed: %s", dev_err());
         e->dc.b_cache = e->base_cache; e->dc.b_tri = e->base_tri; e->dc.b_pair = e->base_pair; e->dc.b_piv = e->base_piv;
         e->base_ready = true;
       }
     }
   }
   return PPN_OK;
+}
+
+// Schur updates of the SHARED schedule re-packed into fewer rounds of 64 (host side, once per engine).  A triple of pivot k
+// (level L) -- A(i,j) -= A(i,k) U'(k,j) -- may run in the Schur phase of any level from L up to the level before A(i,j) is first
+// READ (as the pivot block, a pair entry or a triple operand of the earlier of i and j; by the dense tail), so the few records a
+// level holds beyond a multiple of 64 -- a whole round of phase 2 for a handful of lanes -- move on to a later level that has lanes
+// to spare.  IEEE-118: 14 rounds per factorisation -> 11.  Only the order of the atomic adds into a block changes.
+static int rebalance_base_triples(ppn_engine* e) {
+  const DevCase& d = e->dc;
+  if (getenv("PPN_NO_REBALANCE")) return 0;
+  std::vector<u8> cache((size_t)d.cache_stride);
+  if (dev_d2h(cache.data(), e->base_cache, cache.size(), e->stream)) return -1;
+  const int* hdr = (const int*)cache.data();
+  const int n = hdr[1], nnzF = hdr[2], nla = hdr[4], n_pairs = hdr[5], n_tri = hdr[6], ltail = e->newton ? hdr[7] : nla;
+  if (n <= 0 || nla <= 1 || n_tri <= 0 || ltail <= 1) return 0;
+  unsigned* lvl = (unsigned*)(cache.data() + d.co_lvl);
+  std::vector<unsigned> piv((size_t)n);
+  std::vector<u64> pair((size_t)n_pairs > 0 ? n_pairs : 1), tri((size_t)n_tri);
+  if (dev_d2h(piv.data(), e->base_piv, sizeof(unsigned) * (size_t)n, e->stream)) return -1;
+  if (n_pairs > 0 && dev_d2h(pair.data(), e->base_pair, sizeof(u64) * (size_t)n_pairs, e->stream)) return -1;
+  if (dev_d2h(tri.data(), e->base_tri, sizeof(u64) * (size_t)n_tri, e->stream)) return -1;
+  auto lp = [&](int lv) { return (int)(lvl[2 * lv] & 0xFFu); };
+  auto lm = [&](int lv) { return (int)(lvl[2 * lv] >> 8); };
+  auto lt = [&](int lv) { return (int)lvl[2 * lv + 1]; };
+  // first level at which a matrix entry is read
+  const int INF = 1 << 30;
+  std::vector<int> first((size_t)nnzF + 1, INF);
+  auto rd = [&](unsigned en, int lv) { if (en <= (unsigned)nnzF && lv < first[en]) first[en] = lv; };
+  for (int lv = 0; lv < nla; ++lv) {
+    for (int q = lp(lv); q < lp(lv + 1); ++q) rd(piv[q] & 0xFFFFu, lv);
+    for (int m = lm(lv); m < lm(lv + 1); ++m) { rd((unsigned)(pair[m] & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 16) & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 32) & 0xFFFFu), lv); }
+    for (int t = lt(lv); t < lt(lv + 1); ++t) { rd((unsigned)((tri[t] >> 16) & 0xFFFFu), lv); rd((unsigned)((tri[t] >> 32) & 0xFFFFu), lv); }
+  }
+  struct Rec { u64 r; int last; };      // last level whose Schur phase may hold the record
+  std::vector<std::vector<Rec>> out((size_t)ltail);
+  std::vector<Rec> carry;
+  long rounds_before = 0, rounds_after = 0;
+  for (int lv = 0; lv < ltail; ++lv) {
+    const int n_native = lt(lv + 1) - lt(lv);
+    rounds_before += (n_native + 63) / 64;
+    std::vector<Rec> cand = carry;
+    carry.clear();
+    for (int t = lt(lv); t < lt(lv + 1); ++t) {
+      const int fr = first[(size_t)(tri[t] & 0xFFFFu)];
+      int last = (fr < ltail ? fr : ltail) - 1;
+      if (last < lv) last = lv;         // (cannot happen: the target of a level's update is read by a later level)
+      cand.push_back(Rec{tri[t], last});
+    }
+    const int T = (int)cand.size();
+    int x = (lv + 1 < ltail) ? T % 64 : 0;       // records beyond the last full round
+    if (x > 0) {
+      // the x most flexible records move on -- if there are that many that may
+      std::vector<int> idx;
+      for (int c = 0; c < T; ++c) if (cand[c].last > lv) idx.push_back(c);
+      if ((int)idx.size() >= x) {
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cand[a].last > cand[b].last; });
+        std::vector<char> go((size_t)T, 0);
+        for (int c = 0; c < x; ++c) go[idx[c]] = 1;
+        for (int c = 0; c < T; ++c) (go[c] ? carry : out[lv]).push_back(cand[c]);
+      } else {
+        out[lv] = cand;
+      }
+    } else {
+      out[lv] = cand;
+    }
+    rounds_after += ((int)out[lv].size() + 63) / 64;
+  }
+  if (!carry.empty() || rounds_after >= rounds_before) return 0;      // nothing gained: the schedule stays as built
+  std::vector<u64> tri2 = tri;
+  int pos = 0;
+  for (int lv = 0; lv < ltail; ++lv) {
+    lvl[2 * lv + 1] = (unsigned)pos;
+    for (const Rec& r : out[lv]) tri2[(size_t)pos++] = r.r;
+  }
+  if (pos != lt(ltail)) return -1;      // (the records of the levels of the dense tail and beyond stay where they are)
+  if (getenv("PPN_VERBOSE")) fprintf(stderr, "[ppn] shared schedule: Schur rounds %ld -> %ld\n", rounds_before, rounds_after);
+  if (dev_h2d(e->base_tri, tri2.data(), sizeof(u64) * (size_t)n_tri, e->stream)) return -1;
+  if (dev_h2d(e->base_cache + d.co_lvl, lvl, sizeof(unsigned) * 2 * (size_t)(nla + 1), e->stream)) return -1;
+  return 0;
 }
 
 static int copy_state(ppn_engine* e, DevState* dst, const DevState* src) {
