@@ -636,3 +636,38 @@ def check_deferred_restart(lib_path, envname='default118', steps=30, batch=24, b
             assert np.array_equal(a.read('FLAG', simulation=True), b.read('FLAG', simulation=True))
     assert n_done > 0
     return n_done
+
+
+def check_repacked_schedule(lib_path, envname='default118', steps=12, batch=16):
+    """The shared schedule with its Schur updates re-packed into fewer rounds (rebalance_base_triples, ppn_engine.hip) against the
+    schedule as built (PPN_NO_REBALANCE=1): a different order of the atomic adds into a block and nothing else -- flags, line
+    status, counters, cumulative solve and Newton-iteration counts identical, voltages to 1e-10; and both against the C oracle."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
+    with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
+        kw = {'thermal_limits': np.asarray(json.load(f)['limits_a'])}
+    slots, t0 = default_assignment(np.arange(batch) * 11, chronics)
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, max_active_buses=case.nS, **kw)
+    a.reset(chronic_slot=slots, t0=t0)                 # (the shared schedule is adopted, and re-packed, by the first reset)
+    os.environ['PPN_NO_REBALANCE'] = '1'
+    try:
+        b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, max_active_buses=case.nS, **kw)
+        b.reset(chronic_slot=slots, t0=t0)
+    finally:
+        del os.environ['PPN_NO_REBALANCE']
+    orc = engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics, **kw)
+    orc.reset(chronic_slot=slots, t0=t0)
+    act = np.zeros((batch, case.action_length), dtype=np.uint8)
+    exact = ('DONE', 'FLAG', 'LINES_STATUS', 'RECONNECTABLE', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES', 'N_ITERS', 'CASCADE_DEPTH')
+    for t in range(steps):
+        for e in (a, b, orc):
+            e.step(act, auto_reset=True)
+        for f in exact:
+            assert np.array_equal(a.read(f), b.read(f)), (t, f)
+            assert np.array_equal(a.read(f), orc.read(f)), (t, f, 'oracle')
+        va, vb = a.read('VM'), b.read('VM')
+        assert np.allclose(va, vb, rtol=0, atol=1e-10, equal_nan=True), (t, float(np.nanmax(np.abs(va - vb))))
+    return int(a.read('N_SOLVES').sum())

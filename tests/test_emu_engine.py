@@ -130,3 +130,8 @@ def test_emu_deferred_restart_equals_fused(emu_lib):
     assert ec.check_deferred_restart(emu_lib, steps=16, batch=6) > 0
     assert ec.check_deferred_restart(emu_lib, 'default14_for_tests_alpha', steps=40, batch=8, bench_limits=False, max_active_buses=0,
                                      random_acts=True) > 0
+
+
+def test_emu_repacked_schedule(emu_lib):
+    """Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle."""
+    assert ec.check_repacked_schedule(emu_lib, steps=6, batch=6) > 0
