@@ -896,81 +896,161 @@ extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const
   return PPN_OK;
 }
 
-// Schur updates of the SHARED schedule re-packed into fewer rounds of 64 (host side, once per engine).  A triple of pivot k
-// (level L) -- A(i,j) -= A(i,k) U'(k,j) -- may run in the Schur phase of any level from L up to the level before A(i,j) is first
-// READ (as the pivot block, a pair entry or a triple operand of the earlier of i and j; by the dense tail), so the few records a
-// level holds beyond a multiple of 64 -- a whole round of phase 2 for a handful of lanes -- move on to a later level that has lanes
-// to spare.  IEEE-118: 14 rounds per factorisation -> 11.  Only the order of the atomic adds into a block changes.
+// The SHARED schedule re-packed into fewer rounds of 64 lanes (host side, once per engine; PPN_NO_REBALANCE=1 keeps it as built).
+// (1) Pivots.  The static level of a busbar is the earliest it can be eliminated at; it may be eliminated at any level up to the
+//     one before its first later neighbour's.  Pivots with that slack leave a level whose pair list overflows a multiple of 64
+//     (IEEE-118: level 0 holds 99 pairs -- a second round of phase 1 and of the backward pass for 35 lanes) for later levels
+//     with lanes to spare, the most flexible first; a pivot takes its pair and triple records along.
+// (2) Schur updates.  A triple of pivot k (level L) -- A(i,j) -= A(i,k) U'(k,j) -- may run in the Schur phase of any level from
+//     L up to the level before A(i,j) is first READ (as the pivot block, a pair entry or a triple operand of the earlier of i
+//     and j; by the dense tail), so the records a level holds beyond a multiple of 64 move on the same way.  IEEE-118: 15
+//     rounds of phase 2 per factorisation -> 11.
+// Dependencies are untouched; only the order of the atomic adds into a block (and into a right-hand-side entry) changes.
 static int rebalance_base_triples(ppn_engine* e) {
   const DevCase& d = e->dc;
   if (getenv("PPN_NO_REBALANCE")) return 0;
   std::vector<u8> cache((size_t)d.cache_stride);
   if (dev_d2h(cache.data(), e->base_cache, cache.size(), e->stream)) return -1;
   const int* hdr = (const int*)cache.data();
-  const int n = hdr[1], nnzF = hdr[2], nla = hdr[4], n_pairs = hdr[5], n_tri = hdr[6], ltail = e->newton ? hdr[7] : nla;
-  if (n <= 0 || nla <= 1 || n_tri <= 0 || ltail <= 1) return 0;
+  const int n = hdr[1], nnzF = hdr[2], nla = hdr[4], n_pairs = hdr[5], n_tri = hdr[6];
+  const int ltail = hdr[7];      // levels below the dense tail: records only move among those (the Newton and fast-decoupled factorisations stop there;
+                                 // the DC one runs every level, for which the moves are as valid)
+  if (n <= 0 || nla <= 1 || n_tri <= 0 || n_pairs <= 0 || ltail <= 1) return 0;
   unsigned* lvl = (unsigned*)(cache.data() + d.co_lvl);
   std::vector<unsigned> piv((size_t)n);
-  std::vector<u64> pair((size_t)n_pairs > 0 ? n_pairs : 1), tri((size_t)n_tri);
+  std::vector<u64> pair((size_t)n_pairs), tri((size_t)n_tri);
   if (dev_d2h(piv.data(), e->base_piv, sizeof(unsigned) * (size_t)n, e->stream)) return -1;
-  if (n_pairs > 0 && dev_d2h(pair.data(), e->base_pair, sizeof(u64) * (size_t)n_pairs, e->stream)) return -1;
+  if (dev_d2h(pair.data(), e->base_pair, sizeof(u64) * (size_t)n_pairs, e->stream)) return -1;
   if (dev_d2h(tri.data(), e->base_tri, sizeof(u64) * (size_t)n_tri, e->stream)) return -1;
-  auto lp = [&](int lv) { return (int)(lvl[2 * lv] & 0xFFu); };
-  auto lm = [&](int lv) { return (int)(lvl[2 * lv] >> 8); };
-  auto lt = [&](int lv) { return (int)lvl[2 * lv + 1]; };
-  // first level at which a matrix entry is read
+  std::vector<int> Lp((size_t)nla + 1), Lm((size_t)nla + 1), Lt((size_t)nla + 1);
+  for (int lv = 0; lv <= nla; ++lv) { Lp[lv] = (int)(lvl[2 * lv] & 0xFFu); Lm[lv] = (int)(lvl[2 * lv] >> 8); Lt[lv] = (int)lvl[2 * lv + 1]; }
+  if (Lp[nla] != n || Lm[nla] != n_pairs || Lt[nla] != n_tri) return 0;
+  auto rounds = [](int c) { return (c + 63) / 64; };
   const int INF = 1 << 30;
-  std::vector<int> first((size_t)nnzF + 1, INF);
+
+  // ---- (1) pivots ------------------------------------------------------------------------------------------------------
+  std::vector<int> lev_of(256, INF), E(256, INF), latest(256, 0), deg(256, 0);
+  std::vector<std::vector<u64>> pairs_of(256), tris_of(256);
+  std::vector<unsigned> piv_of(256, 0);
+  std::vector<int> order_k;               // pivots in list order
+  for (int lv = 0; lv < nla; ++lv) for (int q = Lp[lv]; q < Lp[lv + 1]; ++q) { const int k = (int)((piv[q] >> 16) & 0xFFu); lev_of[k] = lv; piv_of[k] = piv[q]; order_k.push_back(k); }
+  for (int m = 0; m < n_pairs; ++m) pairs_of[(size_t)(pair[m] >> 56)].push_back(pair[m]);
+  for (int t = 0; t < n_tri; ++t) tris_of[(size_t)(tri[t] >> 56)].push_back(tri[t]);
+  for (int k : order_k) {
+    int first_nb = INF;
+    for (u64 r : pairs_of[k]) first_nb = std::min(first_nb, lev_of[(size_t)((r >> 48) & 0xFFu)]);
+    deg[k] = (int)pairs_of[k].size();
+    E[k] = lev_of[k];
+    latest[k] = lev_of[k] >= ltail ? lev_of[k] : std::min(first_nb - 1, ltail - 1);
+    if (latest[k] < lev_of[k]) latest[k] = lev_of[k];
+  }
+  long pr_before = 0, pr_after = 0;
+  for (int lv = 0; lv < ltail; ++lv) pr_before += rounds(Lm[lv + 1] - Lm[lv]);
+  {
+    std::vector<std::vector<int>> pool((size_t)ltail);
+    for (int k : order_k) if (lev_of[k] < ltail) pool[(size_t)lev_of[k]].push_back(k);
+    for (int lv = 0; lv + 1 < ltail; ++lv) {
+      int np = 0;
+      for (int k : pool[lv]) np += deg[k];
+      const int excess = np > 64 ? np % 64 : 0;       // pairs beyond the last full round (a level of one round gains nothing)
+      if (excess == 0) continue;
+      std::vector<int> cand;
+      for (int k : pool[lv]) if (latest[k] > lv && deg[k] > 0) cand.push_back(k);
+      std::stable_sort(cand.begin(), cand.end(), [&](int a_, int b_) { return latest[a_] > latest[b_]; });
+      int moved = 0;
+      std::vector<int> go;
+      for (int k : cand) { if (moved >= excess) break; go.push_back(k); moved += deg[k]; }
+      if (moved < excess) continue;
+      for (int k : go) { E[k] = lv + 1; pool[lv].erase(std::find(pool[lv].begin(), pool[lv].end(), k)); pool[lv + 1].push_back(k); }
+    }
+    bool ok = true;
+    for (int lv = 0; lv < ltail; ++lv) {
+      int np = 0;
+      for (int k : pool[lv]) np += deg[k];
+      pr_after += rounds(np);
+      if ((int)pool[lv].size() > 64 && (int)pool[lv].size() > Lp[lv + 1] - Lp[lv]) ok = false;     // (never a second round of pivots)
+      if (pool[lv].empty()) ok = false;                                                             // (the level table keeps its shape)
+    }
+    if (!ok || pr_after >= pr_before) { for (int k : order_k) E[k] = lev_of[k]; pr_after = pr_before; }
+    else {
+      // lists in the new level order (a level: its own pivots in their old order, then the ones that moved in)
+      std::vector<unsigned> piv2; std::vector<u64> pair2, tri2;
+      std::vector<int> Lp2((size_t)nla + 1), Lm2((size_t)nla + 1), Lt2((size_t)nla + 1);
+      for (int lv = 0; lv < nla; ++lv) {
+        Lp2[lv] = (int)piv2.size(); Lm2[lv] = (int)pair2.size(); Lt2[lv] = (int)tri2.size();
+        for (int pass = 0; pass < 2; ++pass)
+          for (int k : order_k) {
+            if (E[k] != lv || (pass == 0) != (lev_of[k] == lv)) continue;
+            piv2.push_back(piv_of[k]);
+            pair2.insert(pair2.end(), pairs_of[k].begin(), pairs_of[k].end());
+            tri2.insert(tri2.end(), tris_of[k].begin(), tris_of[k].end());
+          }
+      }
+      Lp2[nla] = (int)piv2.size(); Lm2[nla] = (int)pair2.size(); Lt2[nla] = (int)tri2.size();
+      if (Lp2[nla] != n || Lm2[nla] != n_pairs || Lt2[nla] != n_tri) return -1;
+      piv.swap(piv2); pair.swap(pair2); tri.swap(tri2); Lp.swap(Lp2); Lm.swap(Lm2); Lt.swap(Lt2);
+    }
+  }
+
+  // ---- (2) Schur updates -----------------------------------------------------------------------------------------------
+  std::vector<int> first((size_t)nnzF + 1, INF);      // first level at which a matrix entry is read
   auto rd = [&](unsigned en, int lv) { if (en <= (unsigned)nnzF && lv < first[en]) first[en] = lv; };
   for (int lv = 0; lv < nla; ++lv) {
-    for (int q = lp(lv); q < lp(lv + 1); ++q) rd(piv[q] & 0xFFFFu, lv);
-    for (int m = lm(lv); m < lm(lv + 1); ++m) { rd((unsigned)(pair[m] & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 16) & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 32) & 0xFFFFu), lv); }
-    for (int t = lt(lv); t < lt(lv + 1); ++t) { rd((unsigned)((tri[t] >> 16) & 0xFFFFu), lv); rd((unsigned)((tri[t] >> 32) & 0xFFFFu), lv); }
+    for (int q = Lp[lv]; q < Lp[lv + 1]; ++q) rd(piv[q] & 0xFFFFu, lv);
+    for (int m = Lm[lv]; m < Lm[lv + 1]; ++m) { rd((unsigned)(pair[m] & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 16) & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 32) & 0xFFFFu), lv); }
+    for (int t = Lt[lv]; t < Lt[lv + 1]; ++t) { rd((unsigned)((tri[t] >> 16) & 0xFFFFu), lv); rd((unsigned)((tri[t] >> 32) & 0xFFFFu), lv); }
   }
   struct Rec { u64 r; int last; };      // last level whose Schur phase may hold the record
   std::vector<std::vector<Rec>> out((size_t)ltail);
   std::vector<Rec> carry;
-  long rounds_before = 0, rounds_after = 0;
+  long tr_before = 0, tr_after = 0;
   for (int lv = 0; lv < ltail; ++lv) {
-    const int n_native = lt(lv + 1) - lt(lv);
-    rounds_before += (n_native + 63) / 64;
+    tr_before += rounds(Lt[lv + 1] - Lt[lv]);
     std::vector<Rec> cand = carry;
     carry.clear();
-    for (int t = lt(lv); t < lt(lv + 1); ++t) {
+    for (int t = Lt[lv]; t < Lt[lv + 1]; ++t) {
       const int fr = first[(size_t)(tri[t] & 0xFFFFu)];
       int last = (fr < ltail ? fr : ltail) - 1;
       if (last < lv) last = lv;         // (cannot happen: the target of a level's update is read by a later level)
       cand.push_back(Rec{tri[t], last});
     }
     const int T = (int)cand.size();
-    int x = (lv + 1 < ltail) ? T % 64 : 0;       // records beyond the last full round
+    const int x = (lv + 1 < ltail) ? T % 64 : 0;       // records beyond the last full round
+    bool moved = false;
     if (x > 0) {
-      // the x most flexible records move on -- if there are that many that may
       std::vector<int> idx;
       for (int c = 0; c < T; ++c) if (cand[c].last > lv) idx.push_back(c);
-      if ((int)idx.size() >= x) {
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cand[a].last > cand[b].last; });
+      if ((int)idx.size() >= x) {                      // the x most flexible records move on -- if there are that many that may
+        std::stable_sort(idx.begin(), idx.end(), [&](int a_, int b_) { return cand[a_].last > cand[b_].last; });
         std::vector<char> go((size_t)T, 0);
         for (int c = 0; c < x; ++c) go[idx[c]] = 1;
         for (int c = 0; c < T; ++c) (go[c] ? carry : out[lv]).push_back(cand[c]);
-      } else {
-        out[lv] = cand;
+        moved = true;
       }
-    } else {
+    }
+    if (!moved) {
+      // records that were carried here and cannot wait any longer stay; so does everything else
       out[lv] = cand;
     }
-    rounds_after += ((int)out[lv].size() + 63) / 64;
+    tr_after += rounds((int)out[lv].size());
   }
-  if (!carry.empty() || rounds_after >= rounds_before) return 0;      // nothing gained: the schedule stays as built
-  std::vector<u64> tri2 = tri;
-  int pos = 0;
-  for (int lv = 0; lv < ltail; ++lv) {
-    lvl[2 * lv + 1] = (unsigned)pos;
-    for (const Rec& r : out[lv]) tri2[(size_t)pos++] = r.r;
+  const bool tri_repacked = carry.empty() && tr_after < tr_before;
+  if (tri_repacked) {
+    int pos = 0;
+    std::vector<u64> tri2 = tri;
+    for (int lv = 0; lv < ltail; ++lv) { Lt[lv] = pos; for (const Rec& r : out[lv]) tri2[(size_t)pos++] = r.r; }
+    if (pos != Lt[ltail]) return -1;      // (the records of the levels of the dense tail and beyond stay where they are)
+    tri.swap(tri2);
+  } else {
+    tr_after = tr_before;
   }
-  if (pos != lt(ltail)) return -1;      // (the records of the levels of the dense tail and beyond stay where they are)
-  if (getenv("PPN_VERBOSE")) fprintf(stderr, "[ppn] shared schedule: Schur rounds %ld -> %ld\n", rounds_before, rounds_after);
-  if (dev_h2d(e->base_tri, tri2.data(), sizeof(u64) * (size_t)n_tri, e->stream)) return -1;
+  if (pr_after == pr_before && !tri_repacked) return 0;      // nothing gained: the schedule stays as built
+  if (getenv("PPN_VERBOSE"))
+    fprintf(stderr, "[ppn] shared schedule: rounds of phase 1 %ld -> %ld, of phase 2 %ld -> %ld\n", pr_before, pr_after, tr_before, tr_after);
+  for (int lv = 0; lv <= nla; ++lv) { lvl[2 * lv] = (unsigned)Lp[lv] | ((unsigned)Lm[lv] << 8); lvl[2 * lv + 1] = (unsigned)Lt[lv]; }
+  if (dev_h2d(e->base_piv, piv.data(), sizeof(unsigned) * (size_t)n, e->stream)) return -1;
+  if (dev_h2d(e->base_pair, pair.data(), sizeof(u64) * (size_t)n_pairs, e->stream)) return -1;
+  if (dev_h2d(e->base_tri, tri.data(), sizeof(u64) * (size_t)n_tri, e->stream)) return -1;
   if (dev_h2d(e->base_cache + d.co_lvl, lvl, sizeof(unsigned) * 2 * (size_t)(nla + 1), e->stream)) return -1;
   return 0;
 }

@@ -638,7 +638,7 @@ def check_deferred_restart(lib_path, envname='default118', steps=30, batch=24, b
     return n_done
 
 
-def check_repacked_schedule(lib_path, envname='default118', steps=12, batch=16):
+def check_repacked_schedule(lib_path, envname='default118', steps=12, batch=16, solver='newton'):
     """The shared schedule with its Schur updates re-packed into fewer rounds (rebalance_base_triples, ppn_engine.hip) against the
     schedule as built (PPN_NO_REBALANCE=1): a different order of the atomic adds into a block and nothing else -- flags, line
     status, counters, cumulative solve and Newton-iteration counts identical, voltages to 1e-10; and both against the C oracle."""
@@ -646,7 +646,7 @@ def check_repacked_schedule(lib_path, envname='default118', steps=12, batch=16):
     import os
     from helpers import ENVS
     from pypownet_amd.batched import default_assignment
-    case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
+    case, cfg, chronics = load_env(envname, conf={'solver': solver})
     with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
         kw = {'thermal_limits': np.asarray(json.load(f)['limits_a'])}
     slots, t0 = default_assignment(np.arange(batch) * 11, chronics)

@@ -132,6 +132,7 @@ def test_emu_deferred_restart_equals_fused(emu_lib):
                                      random_acts=True) > 0
 
 
-def test_emu_repacked_schedule(emu_lib):
-    """Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle."""
-    assert ec.check_repacked_schedule(emu_lib, steps=6, batch=6) > 0
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_emu_repacked_schedule(emu_lib, solver):
+    """Pivots and Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle."""
+    assert ec.check_repacked_schedule(emu_lib, steps=6, batch=6, solver=solver) > 0

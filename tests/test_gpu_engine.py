@@ -171,9 +171,11 @@ def test_gpu_tuned_pattern_capacity():
     assert st['split_buses'] > 0
 
 
-def test_gpu_repacked_schedule():
-    """Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle (IEEE-118, cascade limits)."""
-    assert ec.check_repacked_schedule(HIP, steps=20, batch=64) > 0
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_repacked_schedule(solver):
+    """Pivots and Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle (IEEE-118,
+    cascade limits)."""
+    assert ec.check_repacked_schedule(HIP, steps=20, batch=64, solver=solver) > 0
 
 
 class _DLPackOnly(object):
