@@ -33,6 +33,12 @@ struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LD
 #define LANE_READ(v, l) ((v)[(l)])          // value held by lane l (l wave-uniform)
 #define LANE_READ_D(arr, j, l) ((arr)[(l)][(j)])   // element j of a per-lane double array, as held by lane l
 #define LANE_READ_DV(v, l) ((v)[(l)])
+// references to per-lane state in helper signatures; broadcasts inside a row of 16 lanes (lane T of the row), T a compile-time constant
+#define LANE_ARR_REF(type, name, n) type (&name)[64][n]
+#define LANE_VAR_REF(type, name) type (&name)[64]
+#define LANE_BCAST16_A(arr, j, T) ((arr)[(lane & ~15) + (T)][(j)])
+#define LANE_FMAC16_A(arr, j, T, mul) ((arr)[lane][(j)] = __builtin_fma((arr)[(lane & ~15) + (T)][(j)], (mul), (arr)[lane][(j)]))
+#define LANE_FMAC16_V(acc, src, T, mul) ((acc)[lane] = __builtin_fma((src)[(lane & ~15) + (T)], (mul), (acc)[lane]))
 #define PPN_UNI(x) (x)
 static inline int ppn_popc(u64 x) { return __builtin_popcountll(x); }
 static inline int ppn_ctz(u64 x) { return __builtin_ctzll(x); }
@@ -69,6 +75,25 @@ __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" :
 #define LANE_READ(v, l) ((unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
 #define LANE_READ_D(arr, j, l) ppn_readlane_d((arr)[(j)], (l))
 #define LANE_READ_DV(v, l) ppn_readlane_d((v), (l))
+#define LANE_ARR_REF(type, name, n) type (&name)[n]
+#define LANE_VAR_REF(type, name) type& name
+// DPP row_newbcast: lane T of every row of 16 lanes, as a VGPR operand -- no trip through scalar registers.  The f64 multiply-add
+// takes the broadcast as its DPP source: acc += bcast_T(src) * mul is ONE instruction (v_readlane x 2 + v_fma before).  (A DPP
+// read needs two wait states after a VALU write of its source, and the hazard recogniser does not look into inline assembly:
+// the form for a freshly written source carries its own s_nop.)
+template <int T> __device__ __forceinline__ double ppn_bcast16_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + T, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + T, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int T, bool FRESH> __device__ __forceinline__ void ppn_fmac_bcast16(double& acc, double src, double mul) {
+  // FRESH: `src` may have been written by one of the two instructions before this one
+  if (FRESH) __asm__ volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(T));
+  else __asm__ volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(T));
+}
+#define LANE_BCAST16_A(arr, j, T) ppn_bcast16_d<(T)>((arr)[(j)])
+#define LANE_FMAC16_A(arr, j, T, mul) ppn_fmac_bcast16<(T), false>((arr)[(j)], (arr)[(j)], (mul))      /* src: written a whole elimination step ago */
+#define LANE_FMAC16_V(acc, src, T, mul) ppn_fmac_bcast16<(T), true>((acc), (src), (mul))
 __device__ __forceinline__ double ppn_readlane_d(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
