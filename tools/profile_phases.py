@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-NAMES = ['live buses/types/connectivity', 'schedule check (+rebuild)', '(unused)', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
+NAMES = ['connectivity (adjacency + BFS)', 'schedule check (+rebuild)', 'live buses/injections/types', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
          'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)', 'restart of ended episodes (incl its solves)',
          'cut flags + topology write-back']
 
