@@ -38,6 +38,7 @@ struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LD
 #define LANE_VAR_REF(type, name) type (&name)[64]
 #define LANE_BCAST16_A(arr, j, T) ((arr)[(lane & ~15) + (T)][(j)])
 #define LANE_FMAC16_A(arr, j, T, mul) ((arr)[lane][(j)] = __builtin_fma((arr)[(lane & ~15) + (T)][(j)], (mul), (arr)[lane][(j)]))
+#define LANE_FMAC16_S(acc, T, mul) ((acc)[lane] = __builtin_fma((acc)[(lane & ~15) + (T)], (mul), (acc)[lane]))
 #define LANE_FMAC16_V(acc, src, T, mul) ((acc)[lane] = __builtin_fma((src)[(lane & ~15) + (T)], (mul), (acc)[lane]))
 #define PPN_UNI(x) (x)
 static inline int ppn_popc(u64 x) { return __builtin_popcountll(x); }
@@ -82,17 +83,25 @@ __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" :
 // read needs two wait states after a VALU write of its source, and the hazard recogniser does not look into inline assembly:
 // the form for a freshly written source carries its own s_nop.)
 template <int T> __device__ __forceinline__ double ppn_bcast16_d(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + T, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + T, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
+  double o;      // (inline assembly with its own s_nop, like the multiply-adds below: `v` usually is the result of one of THEIR statements,
+                 //  which the hazard recogniser does not see as a VALU write)
+  __asm__ volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(T));
+  return o;
 }
 template <int T, bool FRESH> __device__ __forceinline__ void ppn_fmac_bcast16(double& acc, double src, double mul) {
   // FRESH: `src` may have been written by one of the two instructions before this one
   if (FRESH) __asm__ volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(T));
   else __asm__ volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(T));
 }
+// acc += bcast_T(acc) * mul, accumulator and DPP source ONE operand.  The s_nop is NOT optional even though the source was
+// computed a whole elimination step ago: the register allocator may place a copy of the accumulator -- a VALU write -- right in
+// front of the statement (seen with a 16-row tail: wrong results in the 5th digit, caught by tools/ubench/dense_tail_test.hip).
+template <int T> __device__ __forceinline__ void ppn_fmac_bcast16_self(double& acc, double mul) {
+  __asm__ volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(mul), "n"(T));
+}
 #define LANE_BCAST16_A(arr, j, T) ppn_bcast16_d<(T)>((arr)[(j)])
-#define LANE_FMAC16_A(arr, j, T, mul) ppn_fmac_bcast16<(T), false>((arr)[(j)], (arr)[(j)], (mul))      /* src: written a whole elimination step ago */
+#define LANE_FMAC16_A(arr, j, T, mul) ppn_fmac_bcast16_self<(T)>((arr)[(j)], (mul))
+#define LANE_FMAC16_S(acc, T, mul) ppn_fmac_bcast16_self<(T)>((acc), (mul))
 #define LANE_FMAC16_V(acc, src, T, mul) ppn_fmac_bcast16<(T), true>((acc), (src), (mul))
 __device__ __forceinline__ double ppn_readlane_d(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));

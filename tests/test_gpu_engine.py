@@ -2,6 +2,8 @@
 the same seeded inputs.  Bars (BASELINE.json north_star): bit-exact line status / topology / counters / flags;
 |dVm| <= 1e-6 p.u. and |dVa| <= 1e-6 rad (measured margins are ~1e-10, the tests use 1e-8 where the two sides
 run the same algorithm)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,7 @@ from test_oracle_known_answers import _basic_topology_policy
 
 pytestmark = pytest.mark.gpu
 HIP = None   # default library path: pypownet_amd/libppn.so
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 
 
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
@@ -176,6 +179,24 @@ def test_gpu_repacked_schedule(solver):
     """Pivots and Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle (IEEE-118,
     cascade limits)."""
     assert ec.check_repacked_schedule(HIP, steps=20, batch=64, solver=solver) > 0
+
+
+@pytest.mark.parametrize('tail_buses', [6, 8])
+def test_gpu_dense_tail_unit(tail_buses):
+    """The register-resident dense tail on its own (tools/ubench/dense_tail_test.hip): tail_eliminate / tail_substitute of the kernel
+    sources on random systems of 2 .. 2 * tail_buses rows with identity rows, against Gaussian elimination on the host.  Holds the
+    DPP hazard the engine tests cannot see at the shipped tail size (a copy the register allocator may place in front of a DPP
+    read): found with a 16-row tail."""
+    import subprocess
+    exe = os.path.join(ROOT, 'build', 'dense_tail_test_m%d' % (2 * tail_buses))
+    src = os.path.join(ROOT, 'tools', 'ubench', 'dense_tail_test.hip')
+    deps = [src] + [os.path.join(ROOT, 'pypownet_amd', 'csrc', f) for f in ('ppn_device.h', 'ppn_solve.inc')]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-w', '-DPPN_TAIL_BUSES=%d' % tail_buses,
+                               src, '-o', exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert out.returncode == 0 and 'FAILED' not in out.stdout, out.stdout
 
 
 class _DLPackOnly(object):
