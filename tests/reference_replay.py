@@ -1,0 +1,293 @@
+"""Replays of the golden runs under tests/golden/reference_runs/ -- recorded from the REFERENCE'S OWN RunEnv / Game / Grid code by
+tools/make_reference_fixtures.py (build container only; the solver underneath was oracle/pf_np.py, so these files pin the
+game-rule layer, not the numeric layer) -- through (a) the numpy oracle and (b) an engine library (HIP product, lane-serial
+emulation build, C oracle), same actions, same protocol (Runner.step, pypownet/runner.py:81-84: a finished episode is passed
+through process_game_over).  Integer fields are compared bit for bit on every step; observation arrays and the floating-point
+grid state on the sampled steps the files hold."""
+import json
+import os
+
+import numpy as np
+
+from helpers import ROOT, load_env
+from oracle import reward_np
+from oracle.game_np import OracleGame, obs_as_array
+
+RUNS = os.path.join(ROOT, 'tests', 'golden', 'reference_runs')
+FLAG_ILLEGAL = 4
+TOL_OBS = 1e-6          # the solver underneath the recorded runs and the oracle's is the same code: agreement is ~1e-12
+TOL_ENGINE_V, TOL_ENGINE_FLOW = 1e-6, 1e-4
+
+
+def scenario_names():
+    return sorted(f[:-4] for f in os.listdir(RUNS) if f.endswith('.npz')) if os.path.isdir(RUNS) else []
+
+
+class Run(object):
+    def __init__(self, name):
+        z = np.load(os.path.join(RUNS, name + '.npz'))
+        self.z = {k: z[k] for k in z.files}
+        self.meta = json.loads(str(self.z['meta']))
+        self.name = name
+        self.steps = len(self.z['done'])
+        n = int(self.z['action_length'])
+        self.actions = np.unpackbits(self.z['action'], axis=1)[:, :n]
+        self.actions_after = np.unpackbits(self.z['action_after'], axis=1)[:, :n]
+        self.sampled = {int(t): k for k, t in enumerate(self.z['sampled_steps'])}
+        self.ended = {int(t): k for k, t in enumerate(self.z['ended_steps'])}
+        self.ended_sampled = {int(t): k for k, t in enumerate(self.z['ended_sampled_steps'])}
+        conf = dict(self.meta['conf'])
+        conf['solver'] = self.meta['solver']
+        self.case, self.conf, self.chronics = load_env(self.meta['fixture_env'], conf=conf)
+        assert [c.name for c in self.chronics] == self.meta['chronics'], 'fixture environment holds another chronic set'
+        self.limits = self.z.get('thermal_limits')
+
+    def oracle_game(self):
+        return OracleGame(self.case, self.conf, self.chronics, game_over_mode=self.meta['game_over_mode'],
+                          thermal_limits=self.limits)
+
+    def int_state(self, prefix, k):
+        z = self.z
+        return {f: z[prefix + f][k] if prefix != 'init_' else z[prefix + f] for f in
+                ('line_status', 'prods_nodes', 'loads_nodes', 'or_nodes', 'ex_nodes', 'reconnectable', 'line_cooldown',
+                 'node_cooldown', 'soft_count', 'timestep_id', 'chronic', 'bus_type')}
+
+    def float_state(self, prefix, k):
+        z = self.z
+        return {f: z[prefix + f][k] if prefix != 'init_' else z[prefix + f] for f in ('vm', 'va', 'pg', 'qg', 'flows')}
+
+    def repaired_action(self, t):
+        """The action object as RunEnv holds it after Game.step: the repair edits it in place (game.py:809-846) -- also when
+        the step then ends in a game over and the flag returned is that exception, not the IllegalActionException."""
+        return self.actions_after[t].astype(np.int64)
+
+
+# ---- (a) the numpy oracle ---------------------------------------------------------------------------------------------------
+def _cmp_oracle_ints(run, g, want, where, after_failure=False):
+    got = dict(line_status=g.line_status, prods_nodes=g.prods_nodes, loads_nodes=g.loads_nodes, or_nodes=g.or_nodes,
+               ex_nodes=g.ex_nodes, reconnectable=g.reconnectable, line_cooldown=g.line_cooldown,
+               node_cooldown=g.node_cooldown, soft_count=g.n_soft_overflowed,
+               timestep_id=-1 if g.current_timestep_id is None else g.current_timestep_id,
+               chronic=g.current_chronic_slot, bus_type=g.bus_type)
+    for k, w in want.items():
+        assert np.array_equal(np.asarray(got[k]).astype(np.int64), np.asarray(w).astype(np.int64)), \
+            '%s: %s differs %s' % (run.name, k, where)
+
+
+def _cmp_oracle_floats(run, g, want, where):
+    act = g.bus_type != 4
+    np.testing.assert_allclose(g.vm[act], want['vm'][act], rtol=0, atol=TOL_OBS, err_msg='%s vm %s' % (run.name, where))
+    np.testing.assert_allclose(g.va[act], want['va'][act], rtol=0, atol=1e-5, err_msg='%s va %s' % (run.name, where))
+    np.testing.assert_allclose(g.pg, want['pg'], rtol=0, atol=TOL_OBS, err_msg='%s pg %s' % (run.name, where))
+    np.testing.assert_allclose(g.qg, want['qg'], rtol=0, atol=TOL_OBS, err_msg='%s qg %s' % (run.name, where))
+    np.testing.assert_allclose(g.flows, want['flows'], rtol=0, atol=TOL_OBS, err_msg='%s flows %s' % (run.name, where))
+
+
+def expected_reward(run, t, n_loads_cut, n_prods_cut, topo_bits, amps, limits, constant):
+    """reward_np on the fixture's flag / masks and the given state: what RunEnv.step's reward list must be."""
+    z = run.z
+    flag = int(z['flag'][t])
+    bits = 0
+    if flag == FLAG_ILLEGAL:
+        bits = (1 if z['ill_too_many'][t] else 0) | (2 if z['ill_broken'][t].any() else 0) | \
+            (4 if z['ill_line_cd'][t].any() else 0) | (8 if z['ill_node_cd'][t].any() else 0)
+    counts = (int(z['ill_broken'][t].sum()), int(z['ill_line_cd'][t].sum()), int(z['ill_node_cd'][t].sum()))
+    a = run.repaired_action(t)
+    c = run.case
+    o = c.nP + c.nL + 2 * c.nl
+    k = reward_np.coefficients(constant)
+    return reward_np.compute_reward(k, flag if flag != FLAG_ILLEGAL else 0, bits, counts, int(a[:o].sum()), int(a[o:].sum()),
+                                    n_loads_cut, n_prods_cut, topo_bits, amps, limits)
+
+
+def replay_oracle(name):
+    run = Run(name)
+    z = run.z
+    g = run.oracle_game()
+    _cmp_oracle_ints(run, g, run.int_state('init_', 0), 'after construction')
+    _cmp_oracle_floats(run, g, run.float_state('init_', 0), 'after construction')
+    np.testing.assert_allclose(obs_as_array(g.export_observation()), z['init_obs'], rtol=0, atol=TOL_OBS)
+    counts = dict(done=0, illegal=0, obs=0, restarts=0)
+    for t in range(run.steps):
+        where = 'at step %d' % t
+        before = (g.reconnectable.copy(), g.line_cooldown.copy(), g.node_cooldown.copy())
+        obs, flag, bits, done = g.step(run.actions[t].astype(np.int64).copy())
+        assert bool(done) == bool(z['done'][t]), '%s: done differs %s' % (name, where)
+        want_flag = int(z['flag'][t])
+        if want_flag == FLAG_ILLEGAL:
+            assert flag == 0 and bits != 0, '%s: the reference flagged an illegal action %s' % (name, where)
+            parts = g.split_action(run.actions[t])
+            lines, subs = parts[4] == 1, g.changed_substations(parts)
+            assert bool(bits & 1) == bool(z['ill_too_many'][t])
+            if not bits & 1:
+                assert np.array_equal(lines & (before[0] > 0), z['ill_broken'][t]), '%s: broken-line mask %s' % (name, where)
+                assert np.array_equal(lines & (before[1] > 0), z['ill_line_cd'][t]), '%s: line-cooldown mask %s' % (name, where)
+                assert np.array_equal(subs & (before[2] > 0), z['ill_node_cd'][t]), '%s: node-cooldown mask %s' % (name, where)
+            counts['illegal'] += 1
+        else:
+            assert flag == want_flag, '%s: flag %d vs %d %s' % (name, flag, want_flag, where)
+            if want_flag == 0:
+                assert bits == 0, '%s: illegal bits the reference did not report %s' % (name, where)
+        _cmp_oracle_ints(run, g, run.int_state('step_', t), where)
+        if not done:
+            iso_l, iso_p = g.isolated_masks()
+            assert int(iso_l.sum()) == int(z['n_loads_cut'][t]) and int(iso_p.sum()) == int(z['n_prods_cut'][t])
+        if t in run.sampled and not done:
+            k = run.sampled[t]
+            _cmp_oracle_floats(run, g, run.float_state('step_', k), where)
+            np.testing.assert_allclose(obs_as_array(obs), z['obs'][k], rtol=0, atol=TOL_OBS, err_msg='%s obs %s' % (name, where))
+            counts['obs'] += 1
+        # reward list of RunEnv.step (environment.py:866-874) from the shipped CustomRewardSignal
+        topo = np.concatenate([g.prods_nodes, g.loads_nodes, g.or_nodes, g.ex_nodes])
+        if not np.isnan(z['reward'][t]).any():
+            iso_l, iso_p = g.isolated_masks()
+            exp = expected_reward(run, t, int(iso_l.sum()), int(iso_p.sum()), topo, g.extract_flows_a(), g.thermal_limits,
+                                  run.case.nS)
+            np.testing.assert_allclose(exp, z['reward'][t], rtol=1e-9, atol=1e-9, err_msg='%s reward %s' % (name, where))
+        if done:
+            counts['done'] += 1
+            epoch0 = g.epoch
+            g.process_game_over()
+            assert g.epoch - epoch0 == int(z['n_restarts'][t]), '%s: number of restarts %s' % (name, where)
+            counts['restarts'] += int(g.epoch - epoch0 > 1)
+            _cmp_oracle_ints(run, g, run.int_state('after_', run.ended[t]), 'after the restart ' + where)
+            if t in run.ended_sampled:
+                k = run.ended_sampled[t]
+                _cmp_oracle_floats(run, g, run.float_state('after_', k), 'after the restart ' + where)
+                np.testing.assert_allclose(obs_as_array(g.export_observation()), z['obs_after'][k], rtol=0, atol=TOL_OBS)
+    return counts
+
+
+# ---- (b) an engine library ---------------------------------------------------------------------------------------------------
+def _engine_ints(eng, chronics, b=0):
+    slot, row = int(eng.read('CHRONIC_SLOT')[b]), int(eng.read('CHRONIC_ROW')[b])
+    return dict(line_status=eng.read('LINES_STATUS')[b], prods_nodes=eng.read('PRODS_NODES')[b],
+                loads_nodes=eng.read('LOADS_NODES')[b], or_nodes=eng.read('LINES_OR_NODES')[b],
+                ex_nodes=eng.read('LINES_EX_NODES')[b], reconnectable=eng.read('RECONNECTABLE')[b],
+                line_cooldown=eng.read('LINE_COOLDOWN')[b], node_cooldown=eng.read('NODE_COOLDOWN')[b],
+                soft_count=eng.read('SOFT_COUNT')[b], chronic=slot,
+                timestep_id=chronics[slot].get_timestep_ids()[row] if row >= 0 else -1, bus_type=eng.read('BUS_TYPE')[b])
+
+
+def _cmp_engine_ints(run, eng, want, where, skip=()):
+    for b in range(eng.batch):
+        got = _engine_ints(eng, run.chronics, b)
+        for k, w in want.items():
+            if k in skip:
+                continue
+            assert np.array_equal(np.asarray(got[k]).astype(np.int64), np.asarray(w).astype(np.int64)), \
+                '%s: %s differs %s (env %d)' % (run.name, k, where, b)
+
+
+def _cmp_engine_floats(run, eng, want, bus_type, where):
+    act = np.asarray(bus_type) != 4
+    vm, va, pg, qg = eng.read('VM'), eng.read('VA'), eng.read('PG'), eng.read('QG')
+    fl = np.stack([eng.read('PF'), eng.read('QF'), eng.read('PT'), eng.read('QT')], axis=2)
+    for b in range(eng.batch):
+        np.testing.assert_allclose(vm[b][act], want['vm'][act], rtol=0, atol=TOL_ENGINE_V, err_msg='%s vm %s' % (run.name, where))
+        np.testing.assert_allclose(np.deg2rad(va[b][act]), np.deg2rad(want['va'][act]), rtol=0, atol=TOL_ENGINE_V,
+                                   err_msg='%s va %s' % (run.name, where))
+        np.testing.assert_allclose(pg[b], want['pg'], rtol=0, atol=TOL_ENGINE_FLOW, err_msg='%s pg %s' % (run.name, where))
+        np.testing.assert_allclose(qg[b], want['qg'], rtol=0, atol=TOL_ENGINE_FLOW, err_msg='%s qg %s' % (run.name, where))
+        np.testing.assert_allclose(fl[b], want['flows'], rtol=0, atol=TOL_ENGINE_FLOW, err_msg='%s flows %s' % (run.name, where))
+
+
+def island_without_reference(run, t):
+    """True when the grid the reference solved at step t holds a connected component without the reference bus.  What PYPOWER
+    does then is SuperLU's rounding luck: the block of the island in B' is singular, ``splu`` raises "exactly singular" (->
+    'The grid is not connexe', grid.py:230) unless the last pivot happens to round to 1e-16 instead of 0 -- then an island
+    WITHOUT INJECTIONS sails through (residual 0 over a tiny pivot) and the game goes on.  The engine defines the outcome
+    (exact connectivity test, 'not connexe'), so such a step is where a replay may legitimately part."""
+    z = run.z
+    ids = [int(v) for v in z['step_bus_ids'][t]]
+    types = z['step_bus_type'][t]
+    on = z['step_line_status'][t] != 0
+    adj = {i: [] for i in ids}
+    for f, to in zip(z['step_f_bus'][t][on], z['step_t_bus'][t][on]):
+        adj[int(f)].append(int(to))
+        adj[int(to)].append(int(f))
+    live = {i for i, ty in zip(ids, types) if ty != 4}
+    ref = [i for i, ty in zip(ids, types) if ty == 3]
+    if not ref:
+        return True
+    seen, stack = {ref[0]}, [ref[0]]
+    while stack:
+        for v in adj[stack.pop()]:
+            if v not in seen:
+                seen.add(v)
+                stack.append(v)
+    return not live.issubset(seen)
+
+
+def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
+    """Every environment of the batch plays the recorded actions; all of them must reproduce the reference's run.  The one
+    class of steps set aside: ``island_without_reference`` (counted in the result; the replay goes on when both sides ended the
+    episode there, and stops when the reference's game went on)."""
+    from harness import engine_with_library
+    run = Run(name)
+    z = run.z
+    eng = engine_with_library(lib_path, run.case, run.conf, batch, chronics=run.chronics, thermal_limits=run.limits,
+                              game_over_mode=run.meta['game_over_mode'])
+    eng.reset()
+    if bool(eng.read('DONE')[0]):
+        eng.process_game_over()
+    _cmp_engine_ints(run, eng, run.int_state('init_', 0), 'after construction')
+    _cmp_engine_floats(run, eng, run.float_state('init_', 0), z['init_bus_type'], 'after construction')
+    if check_obs:
+        np.testing.assert_allclose(eng.observations()[0], z['init_obs'], rtol=0, atol=TOL_ENGINE_FLOW)
+    counts = dict(done=0, illegal=0, obs=0, islands=0, steps=0)
+    for t in range(run.steps):
+        where = 'at step %d' % t
+        eng.step(np.repeat(run.actions[t][None, :], batch, axis=0), auto_reset=False)
+        done, flag, bits = eng.read('DONE'), eng.read('FLAG'), eng.read('ILLEGAL')
+        want_flag = int(z['flag'][t])
+        if int(flag[0]) == 1 and want_flag != 1 and int(eng.read('SOLVE_OUTCOME')[0]) == 2 and island_without_reference(run, t):
+            counts['islands'] += 1
+            if not z['done'][t]:
+                break
+            eng.process_game_over()
+            _cmp_engine_ints(run, eng, run.int_state('after_', run.ended[t]), 'after the restart ' + where)
+            continue
+        counts['steps'] += 1
+        for b in range(batch):
+            assert bool(done[b]) == bool(z['done'][t]), '%s: done differs %s' % (name, where)
+            if want_flag == FLAG_ILLEGAL:
+                assert int(flag[b]) == 0 and int(bits[b]) != 0, '%s: the reference flagged an illegal action %s' % (name, where)
+                want_bits = (1 if z['ill_too_many'][t] else 0) | (2 if z['ill_broken'][t].any() else 0) | \
+                    (4 if z['ill_line_cd'][t].any() else 0) | (8 if z['ill_node_cd'][t].any() else 0)
+                assert int(bits[b]) == want_bits, '%s: illegal bits %d vs %d %s' % (name, bits[b], want_bits, where)
+                if not want_bits & 1:
+                    assert list(eng.read('ILLEGAL_COUNTS')[b][:3]) == [int(z['ill_broken'][t].sum()), int(z['ill_line_cd'][t].sum()),
+                                                                        int(z['ill_node_cd'][t].sum())]
+            else:
+                assert int(flag[b]) == want_flag, '%s: flag %d vs %d %s' % (name, flag[b], want_flag, where)
+                if want_flag == 0:
+                    assert int(bits[b]) == 0
+        counts['illegal'] += int(want_flag == FLAG_ILLEGAL)
+        if not z['done'][t]:
+            _cmp_engine_ints(run, eng, run.int_state('step_', t), where)
+            assert int(eng.read('N_LOADS_CUT')[0]) == int(z['n_loads_cut'][t])
+            assert int(eng.read('N_PRODS_CUT')[0]) == int(z['n_prods_cut'][t])
+            if t in run.sampled:
+                k = run.sampled[t]
+                _cmp_engine_floats(run, eng, run.float_state('step_', k), z['step_bus_type'][t], where)
+                if check_obs:
+                    np.testing.assert_allclose(eng.observations()[0], z['obs'][k], rtol=0, atol=TOL_ENGINE_FLOW,
+                                               err_msg='%s obs %s' % (name, where))
+                    counts['obs'] += 1
+        if check_reward and not np.isnan(z['reward'][t]).any():
+            # the device reward (PPN_F_REWARD) against what the reference's CustomRewardSignal returned
+            np.testing.assert_allclose(eng.read('REWARD')[0], z['reward'][t], rtol=1e-7, atol=1e-6,
+                                       err_msg='%s reward %s' % (name, where))
+        if z['done'][t]:
+            counts['done'] += 1
+            eng.process_game_over()
+            _cmp_engine_ints(run, eng, run.int_state('after_', run.ended[t]), 'after the restart ' + where)
+            if t in run.ended_sampled:
+                k = run.ended_sampled[t]
+                _cmp_engine_floats(run, eng, run.float_state('after_', k), z['after_bus_type'][run.ended[t]],
+                                   'after the restart ' + where)
+                if check_obs:
+                    np.testing.assert_allclose(eng.observations()[0], z['obs_after'][k], rtol=0, atol=TOL_ENGINE_FLOW)
+    eng.close()
+    return counts

@@ -1,0 +1,58 @@
+"""Game-rule parity pinned by the REFERENCE'S OWN CODE.  tests/golden/reference_runs/*.npz were recorded in the build container by
+tools/make_reference_fixtures.py from /root/reference's RunEnv / Game / Grid / reward signals imported in place (gym and pypower
+replaced by in-memory stand-ins; the solver underneath is oracle/pf_np.py, so the numeric layer stays pinned by K1-K4 only):
+16 scenarios on default14 / default30 / default118 and the reference tests' own environments, soft and hard game-over mode,
+FDXB / DC as the reference runs them plus the headline Newton solver, 200-400 random node-splitting / line-switching steps each.
+
+  * CPU: the numpy oracle (oracle/game_np.py) replays every run -- integer fields bit for bit on every step (flags, illegal-action
+    masks, line status, node vectors, the four counters, chronic + timestep id, bus types, number of restarts), observation arrays,
+    grid floats and the reward list to 1e-6 -- and so does the lane-serial emulation build of the kernels and the C oracle;
+  * GPU (-m gpu): libppn.so replays the same action files through the C ABI.
+"""
+import pytest
+
+import reference_replay as rr
+import test_emu_engine
+from harness import ORACLE_LIB
+
+emu_lib = test_emu_engine.emu_lib
+NAMES = rr.scenario_names()
+
+
+def test_fixture_set_is_complete():
+    assert len(NAMES) >= 16
+    envs = {rr.Run(n).meta['fixture_env'] for n in NAMES}
+    assert {'default14', 'default30', 'default118'} <= envs
+    modes = {(rr.Run(n).meta['fixture_env'], rr.Run(n).meta['game_over_mode']) for n in NAMES}
+    assert ('default118', 'soft') in modes and ('default118', 'hard') in modes
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_numpy_oracle_replays_reference_run(name):
+    c = rr.replay_oracle(name)
+    assert c['done'] >= 20 and c['obs'] >= 15, c
+
+
+def _check_counts(name, c):
+    run = rr.Run(name)
+    # at most a couple of islanded solves set aside, and the bulk of the run replayed
+    assert c['islands'] <= 2 and c['steps'] >= 0.9 * run.steps - 1, (name, c)
+    assert c['done'] >= 15, (name, c)
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_emulation_build_replays_reference_run(emu_lib, name):
+    _check_counts(name, rr.replay_engine(emu_lib, name))
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_c_oracle_replays_reference_run(name):
+    _check_counts(name, rr.replay_engine(ORACLE_LIB, name, check_reward=False, check_obs=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES)
+def test_gpu_replays_reference_run(name):
+    c = rr.replay_engine(None, name, batch=3)
+    _check_counts(name, c)
+    assert c['obs'] >= 10, (name, c)

@@ -438,4 +438,5 @@ def test_random_chronic_looping_mode_through_runenv(emu_lib):
             seq.append(env.game.get_current_chronic_name())
         names.append(tuple(seq))
     assert names[0] == names[1]
-    assert len(set(names)) > 1 and set(n for s_ in names for n in s_) == {'a', 'b'}
+    seen = set(n for s_ in names for n in s_)
+    assert len(set(names)) > 1 and len(seen) >= 8 and seen <= set('abcdefghijkl')

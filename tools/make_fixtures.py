@@ -49,7 +49,9 @@ if __name__ == '__main__':
     for t in ['default14_for_tests', 'default14_for_tests_alpha', 'default14_for_tests_beta',
               'default14_for_tests_hard_overflow']:
         emit_env(os.path.join('tests', 'parameters', t), t, ['a'])
-    emit_env(os.path.join('parameters', 'default14'), 'default14', ['a', 'b'], npz=True)
-    emit_env(os.path.join('parameters', 'default118'), 'default118', ['a', 'b'], npz=True)
-    emit_env(os.path.join('parameters', 'default30'), 'default30', ['a'], npz=True)
+    # all twelve chronics of the benchmark environments (environment e plays chronic e mod 12)
+    twelve = list('abcdefghijkl')
+    emit_env(os.path.join('parameters', 'default14'), 'default14', twelve, npz=True)
+    emit_env(os.path.join('parameters', 'default118'), 'default118', twelve, npz=True)
+    emit_env(os.path.join('parameters', 'default30'), 'default30', ['a', 'b', 'c'], npz=True)
     print('fixtures written to', os.path.abspath(OUT))
