@@ -30,6 +30,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 ENV_NAME = 'default118'
 BATCH_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (guides/MI355X_MICROARCH.md)
+FLOP_PER_NR_ITERATION = 55.0e3   # useful flops of one Newton iteration @118 (LU 18 k, Jacobian 22 k, SpMV 4 k, solves 8 k)
 B_IO = 21.6e3                    # compulsory per-step state bytes @118
 B_IT_NR = 72.0e3                 # streaming-model bytes per Newton iteration @118
 
@@ -56,16 +58,26 @@ def bench_limits(case):
     return lim
 
 
+def pmc_summary(batch):
+    """The rocprofv3 PMC passes of this build (tools/collect_profiles.sh; summary committed under profiles/, newest round
+    first): HBM bytes per step-kernel launch (FETCH_SIZE x 2 + WRITE_SIZE) and the SQ busy shares.  None when no summary
+    matches this batch size -- counters cannot be collected from inside the timed run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')), reverse=True):
+        try:
+            with open(path) as f:
+                p = json.load(f)
+            if int(p['batch']) == int(batch):
+                p['file'] = os.path.relpath(path, ROOT)
+                return p
+        except Exception:
+            continue
+    return None
+
+
 def measured_traffic(batch):
-    """HBM bytes per step-kernel launch from the rocprofv3 PMC passes of this build (FETCH_SIZE x 2 + WRITE_SIZE, collected
-    by tools/collect_profiles.sh, summary committed under profiles/); None when no summary matches this batch size --
-    counters cannot be collected from inside the timed run."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')) as f:
-            p = json.load(f)
-        return float(p['hbm_bytes_per_launch']) if int(p['batch']) == int(batch) else None
-    except Exception:
-        return None
+    p = pmc_summary(batch)
+    return float(p['hbm_bytes_per_launch']) if p else None
 
 
 def env_assignment(first, count, chronics):
@@ -187,6 +199,7 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
         eng.step_device(acts[k % n_act].data_ptr(), auto_reset=auto_reset)
     eng.sync()
     s0, i0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
+    st0 = eng.read('N_STEPS').astype(np.int64).sum()
     eng.kernel_time(reset=True)
     n_done, depth_hist = 0, np.zeros(8, dtype=np.int64)
     t = time.perf_counter()
@@ -199,14 +212,20 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
     el = time.perf_counter() - t
     kms, kn = eng.kernel_time(reset=True)
     s1, i1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
-    n_solve, n_it = float(s1 - s0) / (batch * steps), float(i1 - i0) / max(float(s1 - s0), 1.0)
+    # env-steps = Game.step calls the engine EXECUTED (PPN_F_N_STEPS): an environment that is over and whose restart keeps
+    # diverging (PPN_F_DEAD = 3) is launched but does not step, and is not counted
+    executed = int(eng.read('N_STEPS').astype(np.int64).sum() - st0)
+    dead_end = int((eng.read('DEAD') != 0).sum())
+    n_solve, n_it = float(s1 - s0) / max(executed, 1), float(i1 - i0) / max(float(s1 - s0), 1.0)
     b_io, b_nr, b_fd, b_fact = BYTES_8D[envname]
     b_step = b_io + n_solve * (n_it * b_nr if solver == 'newton' else n_it * b_fd + b_fact)
     k_s = (kms / 1e3) / max(kn, 1)
     out = {'config': name, 'env': envname, 'solver': solver, 'batch': batch, 'steps': steps,
-           'env_steps_per_s': batch * steps / el, 'ms_per_step': 1e3 * el / steps, 'step_kernel_ms': 1e3 * k_s,
+           'env_steps_per_s': executed / el, 'env_steps_executed': executed, 'env_steps_launched': batch * steps,
+           'dead_envs_at_end': dead_end, 'ms_per_step': 1e3 * el / steps, 'step_kernel_ms': 1e3 * k_s,
            'solves_per_step': n_solve, 'iters_per_solve': n_it, 'lds_bytes_per_env': eng.lds_bytes,
-           'algorithmic_bytes_per_env_step': b_step, 'roofline_frac': batch * b_step / k_s / 1e9 / HBM_PEAK_GBS,
+           'algorithmic_bytes_per_env_step': b_step,
+           'roofline_frac': (executed / float(steps)) * b_step / k_s / 1e9 / HBM_PEAK_GBS,
            'engine_capacity_flags_last_step': int((eng.read('FLAG') == 4).sum())}
     if split:
         out['illegal_fraction_last_step'] = float((eng.read('ILLEGAL') != 0).mean())
@@ -219,7 +238,7 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
         out['engine_capacity_flags_in_%d_watched_steps' % watch_capacity] = raised
     if histogram:
         out['note'] = 'DONE / CASCADE_DEPTH read back every step for the statistics: the rate includes that synchronisation'
-        out['game_over_rate'] = n_done / float(batch * steps)
+        out['game_over_rate'] = n_done / float(max(executed, 1))
         out['cascade_depth_histogram'] = [int(v) for v in depth_hist]
     eng.close()
     return out
@@ -272,13 +291,28 @@ def main():
                          'environments and gathers (done, flag, reward) over RCCL; default: policy per GPU, no collective')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # launched bare (`python bench.py --gpus N`): spawn the N ranks ourselves, one per GPU, the way the driver's launcher
+        # does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...); the exit code is
+        # the launcher's -- non-zero unless all N ranks joined and finished
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d): %d ranks joined' % (world, args.gpus, world))
+    if os.environ.get('PPN_BENCH_BACKEND', 'nccl') == 'nccl' and torch.cuda.is_available() and torch.cuda.device_count() < world:
+        raise SystemExit('--gpus %d needs %d GPUs, %d visible' % (args.gpus, world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
     # PPN_BENCH_BACKEND=gloo: smoke test of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices;
@@ -322,6 +356,7 @@ def main():
         eng.step_device(aptr, auto_reset=AUTO_RESET)
     eng.sync()
     ns0, ni0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
+    nst0 = eng.read('N_STEPS').astype(np.int64).sum()
     eng.kernel_time(reset=True)
 
     exchange = None
@@ -375,7 +410,9 @@ def main():
     ns1, ni1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
     done_now = int(eng.read('DONE').sum())
     depth_now = float(eng.read('CASCADE_DEPTH').mean())
-    stats = torch.tensor([elapsed, float(ns1 - ns0), float(ni1 - ni0), kms, float(klaunch)], dtype=torch.float64,
+    executed = float(eng.read('N_STEPS').astype(np.int64).sum() - nst0)      # Game.step calls executed by this rank (PPN_F_N_STEPS)
+    dead_now = float((eng.read('DEAD') != 0).sum())
+    stats = torch.tensor([elapsed, float(ns1 - ns0), float(ni1 - ni0), kms, float(klaunch), executed, dead_now], dtype=torch.float64,
                          device=('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu')
     if use_dist:
         mx = stats.clone()
@@ -383,17 +420,23 @@ def main():
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0])
-        n_solves, n_iters = float(sm[1]), float(sm[2])
+        n_solves, n_iters, executed_all, dead_all = float(sm[1]), float(sm[2]), float(sm[5]), float(sm[6])
     else:
-        n_solves, n_iters = float(stats[1]), float(stats[2])
+        n_solves, n_iters, executed_all, dead_all = float(stats[1]), float(stats[2]), executed, dead_now
 
     if rank == 0:
-        total_steps = B * world * args.steps
+        # env-steps = steps the engines EXECUTED; equals batch x ranks x K unless an environment sat out a launch waiting for a
+        # restart that keeps diverging (PPN_F_DEAD = 3) -- `dead_envs_at_end` / `env_steps_launched` make that visible
+        total_steps = executed_all
         solves_per_step = n_solves / total_steps
         iters_per_solve = n_iters / max(n_solves, 1.0)
         b_step = B_IO + solves_per_step * iters_per_solve * B_IT_NR          # algorithmic bytes per env-step
         avg_kernel_s = (kms / 1e3) / max(klaunch, 1)                          # rank 0's step kernel, HIP events
-        achieved = B * b_step / avg_kernel_s / 1e9 if avg_kernel_s > 0 else None
+        per_launch = executed / float(args.steps)                              # env-steps rank 0's kernel executes per launch
+        achieved = per_launch * b_step / avg_kernel_s / 1e9 if avg_kernel_s > 0 else None
+        pmc = pmc_summary(B)
+        flop_step = solves_per_step * iters_per_solve * FLOP_PER_NR_ITERATION
+        tflops = per_launch * flop_step / avg_kernel_s / 1e12 if avg_kernel_s > 0 else None
         out = {
             'metric': 'env steps/sec, batched IEEE-118 AC load-flow',
             'value': total_steps / elapsed,
@@ -415,12 +458,27 @@ def main():
                                        'env-sharded x%d, no collective in the step loop') % world,
                        'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
                        'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now, 'auto_reset_mode': AUTO_RESET,
+                       'env_steps_executed': int(executed_all), 'env_steps_launched': B * world * args.steps,
+                       'dead_envs_at_end': int(dead_all), 'n_chronics': len(chronics),
                        'env_assignment_crc32': crcs,
                        'mean_cascade_depth_last_step': depth_now},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
                          'kernel': 'ppn_kernel<W=2,K_STEP>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
-                         'algorithmic_bytes_per_env_step': b_step},
+                         'algorithmic_bytes_per_env_step': b_step,
+                         # the compulsory state I/O alone (an LDS-resident solver legitimately moves fewer bytes
+                         # than the streaming model; traffic / achieved bytes shows it)
+                         'compulsory_io_bytes_per_env_step': B_IO,
+                         'compulsory_io_frac': (per_launch * B_IO / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if avg_kernel_s > 0 else None,
+                         # what actually binds the kernel: FP64 vector issue.  useful flops = SURVEY.md 8d's 55 kflop per
+                         # Newton iteration x measured iterations; valu_busy = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the
+                         # committed PMC pass (None when no pass matches this batch)
+                         'fp64_issue': {'useful_flop_per_env_step': flop_step, 'achieved_tflops': tflops,
+                                        'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
+                                        'frac': (tflops / FP64_VECTOR_PEAK_TFLOPS) if tflops else None,
+                                        'sq_active_inst_any_frac': ((pmc or {}).get('sq_shares_of_wave_cycles') or {}).get('SQ_ACTIVE_INST_ANY'),
+                                        'sq_wait_any_frac': ((pmc or {}).get('sq_shares_of_wave_cycles') or {}).get('SQ_WAIT_ANY'),
+                                        'pmc_file': (pmc or {}).get('file')}},
             'cpu_baseline': None,
         }
         if world == 1:

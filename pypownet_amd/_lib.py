@@ -38,7 +38,15 @@ class PpnRules(C.Structure):
                 ('max_number_actionned_substations', C.c_int32), ('max_number_actionned_lines', C.c_int32),
                 ('max_number_actionned_total', C.c_int32), ('game_over_mode_hard', C.c_int32),
                 ('chronic_looping', C.c_int32), ('max_active_buses', C.c_int32), ('lu_capacity', C.c_int32),
-                ('rng_seed', C.c_int32)]
+                ('rng_seed', C.c_int32), ('q_plane_auto', C.c_int32)]
+
+
+class PpnMpcBatch(C.Structure):
+    """ppn_mpc_batch (include/ppn.h): MATPOWER arrays of n cases in, result arrays out."""
+    _dp = C.POINTER(C.c_double)
+    _fields_ = [('n', C.c_int32), ('bus_cols', C.c_int32), ('gen_cols', C.c_int32), ('branch_cols', C.c_int32),
+                ('bus', _dp), ('gen', _dp), ('branch', _dp), ('bus_out', _dp), ('gen_out', _dp), ('branch_out', _dp),
+                ('success', C.POINTER(C.c_uint8)), ('outcome', C.POINTER(C.c_int32))]
 
 
 class PpnChronic(C.Structure):
@@ -53,11 +61,11 @@ FIELDS = ['VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMP
           'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN',
           'SOFT_COUNT', 'DONE', 'FLAG', 'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT',
           'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE', 'REWARD', 'ILLEGAL_COUNTS',
-          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME']
+          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'DEAD']
 FIELD_ID = {k: i for i, k in enumerate(FIELDS)}
 _F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD'}
 _U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE',
-       'LINE_EVENTS'}
+       'LINE_EVENTS', 'DEAD'}
 
 
 def field_dtype(name):
@@ -72,7 +80,7 @@ def field_dtype(name):
 EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limits', 'ppn_load_chronic', 'ppn_reset',
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
-           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait']
+           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays']
 
 
 def load_library():
@@ -111,6 +119,8 @@ def bind_signatures(lib, full_abi=True):
         lib.ppn_read_observation.restype = C.c_int
         lib.ppn_observation_length.argtypes = [vp, C.c_int32]
         lib.ppn_observation_length.restype = C.c_int32
+        lib.ppn_runpf_arrays.argtypes = [vp, C.POINTER(PpnMpcBatch)]
+        lib.ppn_runpf_arrays.restype = C.c_int
     lib.ppn_set_thermal_limits.argtypes = [vp, C.POINTER(C.c_double)]
     lib.ppn_set_thermal_limits.restype = C.c_int
     lib.ppn_load_chronic.argtypes = [vp, C.c_int32, C.POINTER(PpnChronic)]

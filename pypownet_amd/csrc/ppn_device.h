@@ -240,6 +240,7 @@ struct DevState {
   int *rec, *lcd, *ncd, *soft;     // counters
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
+  int* nstep;                      // Game.step calls this environment has executed since ppn_reset (PPN_F_N_STEPS)
   u8* lev;                         // [nl] PPN_EV_* bits of the last step
   int* src;                        // outcome (SOLVE_*) of the last solve of the last step's cascade
   unsigned* draws;                 // chronics drawn so far by this environment (PPN_LOOP_RANDOM)

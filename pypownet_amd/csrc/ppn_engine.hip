@@ -88,6 +88,10 @@ struct ppn_engine {
   std::vector<int> rowlen_sub, sub_gen_;   // filled-pattern row length of every substation's busbar, production of a substation (-1: none)
   int pattern_pairs = 0;
   int base_fill = 0;
+  // host copies of the case tables the MATPOWER-array boundary decodes against (ppn_mpc.inc)
+  std::vector<long long> h_ids;
+  std::vector<int> h_gen_sub, h_load_sub, h_or_sub, h_ex_sub, h_sub_load;
+  std::vector<double> h_br;         // [nl x 5] r, x, b, tap, shift of the case
   std::string err;
   u8* d_actions = nullptr;
   double* d_obs = nullptr;
@@ -310,6 +314,7 @@ static int alloc_state(ppn_engine* e, DevState* s, size_t B) {
   s->flag = dalloc<int>(e, B); s->ill = dalloc<int>(e, B); s->depth = dalloc<int>(e, B);
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
+  s->nstep = dalloc<int>(e, B);
   s->prow = dalloc<int>(e, B); s->lev = dalloc<u8>(e, B * d.nl); s->src = dalloc<int>(e, B); s->draws = dalloc<unsigned>(e, B);
   s->prof = dalloc<long long>(e, B * 32);
   s->prio = dalloc<float>(e, B);
@@ -370,6 +375,8 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
     case PPN_F_ACTION_SWITCHES: FI(actsw, int, 2, false)
     case PPN_F_LINE_EVENTS: FI(lev, u8, d.nl, false)
     case PPN_F_SOLVE_OUTCOME: FI(src, int, 1, false)
+    case PPN_F_N_STEPS: FI(nstep, int, 1, false)
+    case PPN_F_DEAD: FI(dead, u8, 1, false)
     default: return false;
   }
 #undef FI
@@ -606,9 +613,19 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   d.ECAP = (NB > nS) ? ((ecap + 7) & ~7) : ecap;      // (exact without spare busbars: every 16 bytes count towards the LDS granule)
   d.QCAP = d.ECAP;
   d.LUCAP = 2 * (d.ECAP + d.QCAP);
-  e->auto_qcap = true;      // (rules.lu_capacity sizes the P plane; the Q plane always follows the chronics: size_q_plane)
+  // rules.lu_capacity sizes the P plane.  The Q plane: without spare busbars the chronics give an exact bound (size_q_plane);
+  // with spare busbars it stays full unless the caller opts into the chronic-derived share (rules.q_plane_auto)
+  e->auto_qcap = (NB == nS) || r->q_plane_auto != 0;
   e->pattern_pairs = pairs;
   e->sub_gen_ = sub_gen;
+  e->h_ids = ids; e->h_gen_sub = gen_sub; e->h_load_sub = load_sub; e->h_or_sub = or_sub; e->h_ex_sub = ex_sub;
+  e->h_sub_load = sub_load;
+  e->h_br.resize((size_t)nl * 5);
+  for (int l = 0; l < nl; ++l) {
+    const double* b = br + (size_t)l * rc;
+    double* o = &e->h_br[(size_t)l * 5];
+    o[0] = b[2]; o[1] = b[3]; o[2] = b[4]; o[3] = b[8]; o[4] = b[9];
+  }
   {
     std::vector<int> pos(nS);
     for (int p = 0; p < nS; ++p) pos[order[p]] = p;
@@ -616,6 +633,9 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     for (int s_ = 0; s_ < nS; ++s_) for (int j = 0; j < nS; ++j) e->rowlen_sub[s_] += filled[pos[s_]][j];
   }
   if (d.ECAP > 16000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds 16-bit entry indices"); }
+  // Q relocations are 16-bit byte offsets into the storage (qrel = 16 * ECAP + 16 * (first Q entry of the row - row start),
+  // 0xFFFF = no Q row): both planes have to end below that
+  if (16L * ((long)d.ECAP + d.QCAP) >= 0xFFFFL) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "Newton storage (%d + %d half blocks) exceeds the 16-bit Q relocation offsets", d.ECAP, d.QCAP); }
   {   // schedule cache blob of one environment
     size_t o = 64;                      // header: 16 ints
     auto take = [&](int* off, size_t bytes) { *off = (int)o; o += (bytes + 15) & ~(size_t)15; };
@@ -1238,6 +1258,8 @@ extern "C" int ppn_runpf_batch(ppn_engine* e) {
   if (launch<K_RUNPF>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "runpf kernel launch failed: %s", dev_err());
   return PPN_OK;
 }
+
+#include "ppn_mpc.inc"
 
 extern "C" int ppn_sync(ppn_engine* e) {
   enter(e);

@@ -25,7 +25,7 @@ class EngineError(RuntimeError):
 
 
 def rules_from_conf(conf, without_overflow_cutoff=False, game_over_mode='soft', looping_mode='natural',
-                    max_active_buses=0, lu_capacity=0, rng_seed=0):
+                    max_active_buses=0, lu_capacity=0, rng_seed=0, q_plane_auto=0):
     """Build the ppn_rules struct from a parsed configuration.yaml (pypownet/parameters.py keys)."""
     r = _lib.PpnRules()
     r.mode = MODE_DC if str(conf.get('loadflow_mode', 'AC')).lower() == 'dc' else MODE_AC
@@ -53,6 +53,7 @@ def rules_from_conf(conf, without_overflow_cutoff=False, game_over_mode='soft', 
     r.rng_seed = int(rng_seed) & 0x7fffffff
     r.max_active_buses = int(max_active_buses)
     r.lu_capacity = int(lu_capacity)
+    r.q_plane_auto = int(q_plane_auto)
     return r
 
 
@@ -222,7 +223,31 @@ class Engine(object):
         return out.astype(bool)
 
     def runpf(self):
+        """The bare solve on the CURRENT state of every environment (results through ``read``)."""
         self._check(self._lib.ppn_runpf_batch(self._h), 'ppn_runpf_batch')
+
+    def runpf_arrays(self, bus, gen, branch):
+        """``runpf(mpc, ppopt, '', '')`` / ``rundcpf`` of the reference's seam (pypownet/grid.py:226-229) for n <= batch cases at
+        once: ``bus [n x 2nS x >=13]``, ``gen [n x nP x >=8]``, ``branch [n x nl x >=11]`` MATPOWER arrays with '666'-twin ids
+        -> ``(bus, gen, branch[.. x 17], success[n], outcome[n])`` (include/ppn.h, ppn_runpf_arrays)."""
+        bus = np.ascontiguousarray(bus, dtype=np.float64)
+        gen = np.ascontiguousarray(gen, dtype=np.float64)
+        branch = np.ascontiguousarray(branch, dtype=np.float64)
+        if bus.ndim == 2:
+            bus, gen, branch = bus[None], gen[None], branch[None]
+        n = bus.shape[0]
+        assert gen.shape[0] == n and branch.shape[0] == n
+        io = _lib.PpnMpcBatch()
+        io.n, io.bus_cols, io.gen_cols, io.branch_cols = n, bus.shape[2], gen.shape[2], branch.shape[2]
+        bus_o, gen_o = np.empty_like(bus), np.empty_like(gen)
+        br_o = np.empty((n, branch.shape[1], 17), dtype=np.float64)
+        ok, outcome = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.int32)
+        dp = C.POINTER(C.c_double)
+        io.bus, io.gen, io.branch = bus.ctypes.data_as(dp), gen.ctypes.data_as(dp), branch.ctypes.data_as(dp)
+        io.bus_out, io.gen_out, io.branch_out = bus_o.ctypes.data_as(dp), gen_o.ctypes.data_as(dp), br_o.ctypes.data_as(dp)
+        io.success, io.outcome = ok.ctypes.data_as(C.POINTER(C.c_uint8)), outcome.ctypes.data_as(C.POINTER(C.c_int32))
+        self._check(self._lib.ppn_runpf_arrays(self._h, C.byref(io)), 'ppn_runpf_arrays')
+        return bus_o, gen_o, br_o, ok.astype(bool), outcome
 
     def sync(self):
         self._check(self._lib.ppn_sync(self._h), 'ppn_sync')

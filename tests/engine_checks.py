@@ -142,6 +142,38 @@ def check_hard_overflow_scenario(lib_path, solver):
     assert list(eng.read('LINES_STATUS')[0]) == [1] * 20
 
 
+def check_soft_overflow_scenario(lib_path, solver='fdxb'):
+    """K2 (reference tests/test_core.py:720-738, 784-811, 1322-1328) through the engine: default14_for_tests_alpha, line 6 has a
+    300 A limit, breaks after 2 consecutive overflowed steps and stays broken for 2: on at steps 9 and 10, off at 11 and 12,
+    reconnection refused at (0-based) steps 10 and 11, accepted at agent step 13, the line is on again at step 14."""
+    env = 'default14_for_tests_alpha'
+    eng, case, cfg, chronics = make_engine(lib_path, env, 2, conf={'solver': solver})
+    g = oracle_game(env, conf={'solver': solver})
+    eng.reset()
+    g.process_game_over()
+    _force_game_over(eng)
+    compare_state(eng, [g, g])
+    all_on, l6_off = [1] * 20, [1] * 6 + [0] + [1] * 13
+    ills = []
+    for i in range(1, 15):
+        st = list(eng.read('LINES_STATUS')[1].astype(int))
+        a = do_nothing(case)
+        if i in (9, 10, 14):
+            assert st == all_on, (i, st)
+        if i in (11, 12, 13):
+            assert st == l6_off, (i, st)
+            set_line_switch(case, a, 6, 1)
+        eng.step(np.stack([a, a]))
+        o, f, il, d = g.step(a.copy())
+        assert list(eng.read('FLAG')) == [f, f] == [0, 0] and not d and not eng.read('DONE').any()
+        assert list(eng.read('ILLEGAL')) == [il, il]
+        ills.append(il)
+        compare_state(eng, [g, g])
+    assert [k for k, v in enumerate(ills) if v] == [10, 11]
+    assert int(eng.read('ILLEGAL_COUNTS')[0][0]) == 0          # the last (accepted) reconnection carries no illegal count
+    eng.close()
+
+
 def _force_game_over(eng):
     """Equivalent of calling RunEnv.process_game_over() on a live environment (the reference test harness does
     that before every run): mark every environment dead, then process."""
@@ -491,8 +523,9 @@ def check_random_chronic_looping(lib_path, envname='default14', steps=30, batch=
     lock-step with the C oracle's restatement of the same generator (hard mode, so that draws are frequent), both slots
     must come up, and the draws must be reproducible under the seed and different under another one."""
     cf = {'solver': 'newton'}
-    st = check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, 'newton', seed=seed, conf=cf, max_dropped=batch,
-                                          game_over_mode='hard', looping_mode='random', rng_seed=20260928)
+    st = check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, 'newton', seed=seed, conf=cf,
+                                          max_dropped=max(2, batch // 10), game_over_mode='hard', looping_mode='random',
+                                          rng_seed=20260928)
     assert st['done'] > batch // 4, st
     seqs = []
     for rng_seed in (20260928, 20260928, 7):
@@ -542,7 +575,7 @@ def check_reduced_observation_layouts(lib_path, envname='default118', steps=4, b
 
 
 def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='newton', bench_limits=False, max_active_buses=None,
-                             game_over_mode='soft'):
+                             game_over_mode='soft', conf=None):
     """Lock-step with the C oracle at BASELINE.json's full batch sizes (configs[1]: default14 Newton x 1024 environments,
     configs[2]: default118 Newton x 4096 environments with the cascade limits): do-nothing agent, environment e plays
     chronic (e mod n) from row (37 e) mod T, auto game-over reset.  Flags, line status, counters, chronic
@@ -551,7 +584,7 @@ def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='new
     import os
     from helpers import ENVS
     from pypownet_amd.batched import default_assignment
-    case, cfg, chronics = load_env(envname, conf={'solver': solver})
+    case, cfg, chronics = load_env(envname, conf=dict(conf or {}, solver=solver))
     kw = {}
     if bench_limits:
         with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
@@ -671,3 +704,156 @@ def check_repacked_schedule(lib_path, envname='default118', steps=12, batch=16, 
         va, vb = a.read('VM'), b.read('VM')
         assert np.allclose(va, vb, rtol=0, atol=1e-10, equal_nan=True), (t, float(np.nanmax(np.abs(va - vb))))
     return int(a.read('N_SOLVES').sum())
+
+
+def random_grid_states(envname, n, seed, conf=None, limits=None, warm=9):
+    """n MATPOWER-format (bus, gen, branch) triples of ``envname`` in assorted states -- split nodes, lines out of service,
+    productions off, warm-started voltages -- as the reference's Grid holds them right before ``runpf`` (types synchronised,
+    '666'-twin ids): taken from numpy-oracle games driven by random actions."""
+    rng = np.random.default_rng(seed)
+    case, cfg, chronics = load_env(envname, conf=conf)
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    out = []
+    g = None
+    while len(out) < n:
+        if g is None or rng.random() < 0.15:
+            g = oracle_game(envname, conf=conf, thermal_limits=limits)
+            g.current_timestep_id = None
+            g.chronic = g.chronics[int(rng.integers(len(g.chronics)))]
+            ids = g.chronic.get_timestep_ids()
+            g.load_entries_from_timestep_id(ids[int(rng.integers(len(ids) - 2))])
+        for _ in range(int(rng.integers(1, warm))):
+            a = random_actions(case, rng, 1, p_node=0.8, p_line=0.5)[0]
+            if g.step(a.astype(np.int64))[3]:
+                g.process_game_over()
+        # a state between two solves: next injections loaded, some productions switched off, a few more lines cut
+        g.load_entries_from_next_timestep()
+        off = rng.random(case.nP) < min(0.08, 2.0 / case.nP)
+        g.gen_status[off] = 0
+        g.vg[off] = 0.0
+        g.line_status[rng.random(case.nl) < 1.0 / case.nl] = 0
+        g._sync_bus_types()
+        out.append(g._build_mpc())
+    return case, cfg, out
+
+
+def check_runpf_arrays(lib_path, envname, n, solver='newton', dc=False, seed=77, tol_v=1e-8):
+    """The solve boundary of SURVEY.md 8b (1), ``runpf(mpc, ppopt, '', '') -> (results, success)`` (pypownet/grid.py:226-229):
+    ppn_runpf_arrays on n MATPOWER cases against oracle/pf_np.runpf on the very same arrays."""
+    from oracle import pf_np
+    conf = {'solver': solver}
+    if dc:
+        conf['loadflow_mode'] = 'DC'
+    case, cfg, states = random_grid_states(envname, n, seed, conf=conf)
+    eng = engine_with_library(lib_path, case, cfg, n)               # no chronics: a pure solver
+    bus = np.stack([s[0] for s in states])
+    gen = np.stack([s[1] for s in states])
+    br = np.stack([s[2] for s in states])
+    bo, go, ro, ok, outcome = eng.runpf_arrays(bus, gen, br)
+    alg = pf_np.ALG_NEWTON if solver == 'newton' else pf_np.ALG_FDXB
+    seen = dict(ok=0, failed=0, raised=0, split=0, lines_out=0, prods_off=0, set_aside=0)
+    for i in range(n):
+        try:
+            (b, g_, r), success = pf_np.runpf(case.baseMVA, bus[i], gen[i], br[i], dc=dc, alg=alg, tol=1e-6)
+        except (RuntimeError, RuntimeWarning, IndexError, ValueError):
+            # SuperLU's "exactly singular" on an island without the reference bus is rounding luck (an island may also sail
+            # through); the engine's connectivity test is exact: a raise must be a 'not connexe' here
+            assert outcome[i] == 2 and not ok[i], 'case %d: the reference call raises, engine outcome %d' % (i, outcome[i])
+            assert np.array_equal(bo[i][:, 7:9], bus[i][:, 7:9]) and np.array_equal(ro[i][:, 13:], br[i][:, 13:17])
+            seen['raised'] += 1
+            continue
+        if outcome[i] == 2:                                        # the island sailed through SuperLU (see above)
+            seen['set_aside'] += 1
+            continue
+        if not success and np.nanmin(np.abs(b[:, 7])) < 1e-6:      # collapsed to the spurious |V| = 0 root: set aside
+            seen['set_aside'] += 1
+            continue
+        assert bool(ok[i]) == bool(success), 'case %d: success %d vs %d' % (i, ok[i], success)
+        seen['ok' if success else 'failed'] += 1
+        if not success:
+            continue          # (the last iterate of a diverging solve is noise on both sides)
+        act = bus[i][:, 1] != 4
+        assert np.array_equal(bo[i][:, 1], bus[i][:, 1]), 'case %d: derived bus types' % i
+        np.testing.assert_allclose(bo[i][act, 7], b[act, 7], rtol=0, atol=tol_v, err_msg='Vm of case %d' % i)
+        np.testing.assert_allclose(np.deg2rad(bo[i][act, 8]), np.deg2rad(b[act, 8]), rtol=0, atol=tol_v, err_msg='Va of case %d' % i)
+        assert np.array_equal(bo[i][~act, 7:9], bus[i][~act, 7:9])           # isolated rows come back untouched
+        np.testing.assert_allclose(go[i][:, 1:3], g_[:, 1:3], rtol=0, atol=TOL_FLOW, err_msg='Pg/Qg of case %d' % i)
+        np.testing.assert_allclose(ro[i][:, 13:17], r[:, 13:17], rtol=0, atol=TOL_FLOW, err_msg='flows of case %d' % i)
+        # everything runpf does not touch is handed back as it came
+        keep_b = [c for c in range(bus.shape[2]) if c not in (1, 7, 8)]
+        assert np.array_equal(bo[i][:, keep_b], bus[i][:, keep_b])
+        assert np.array_equal(go[i][:, [0] + list(range(3, gen.shape[2]))], gen[i][:, [0] + list(range(3, gen.shape[2]))])
+        assert np.array_equal(ro[i][:, :13], br[i][:, :13])
+        seen['split'] += int((bus[i][case.nS:, 1] != 4).any())
+        seen['lines_out'] += int((br[i][:, 10] == 0).any())
+        seen['prods_off'] += int((gen[i][:, 7] == 0).any())
+    # malformed input is refused, not guessed at
+    bad = bus.copy()
+    bad[0, 0, 0] += 1
+    with pytest_raises_engine_error():
+        eng.runpf_arrays(bad, gen, br)
+    bad = br.copy()
+    bad[0, 0, 3] *= 1.5
+    with pytest_raises_engine_error():
+        eng.runpf_arrays(bus, gen, bad)
+    eng.close()
+    return seen
+
+
+def pytest_raises_engine_error():
+    import pytest
+    from pypownet_amd.engine import EngineError
+    return pytest.raises(EngineError)
+
+
+def check_restart_goes_on(lib_path, batch=16, steps=8):
+    """The reference restarts for as long as the restarted grid diverges (game.py:776-780).  One engine pass stops after
+    PPN_RESTART_ATTEMPTS; an environment left over (PPN_F_DEAD = 3) is taken up again by the next auto-reset step launch or the
+    next ppn_process_game_over, and meanwhile executes no step (PPN_F_N_STEPS).  Workload: default118 with limits 10 % above
+    the flows of ONE timestep (SURVEY.md 8d's rule), where most episodes collapse at once."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env('default118', conf={'solver': 'newton'})
+    with open(os.path.join(ENVS, 'default118', 'bench_limits_110.json')) as f:
+        lim = np.asarray(json.load(f)['limits_a'])
+    slots, t0 = default_assignment(np.arange(batch), chronics)
+    act = np.zeros((batch, case.action_length), dtype=np.uint8)
+    runs = {}
+    for mode in (1, 2):
+        eng = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, thermal_limits=lim, max_active_buses=case.nS)
+        eng.reset(chronic_slot=slots, t0=t0)
+        hist = []
+        prev = eng.read('N_STEPS').copy()
+        assert not prev.any()
+        for t in range(steps):
+            dead_before = eng.read('DEAD').copy()
+            eng.step(act, auto_reset=mode)
+            n, dead = eng.read('N_STEPS').copy(), eng.read('DEAD').copy()      # (the read settles the deferred restarts)
+            d = n - prev
+            assert ((d == 0) | (d == 1)).all()
+            assert (d[dead_before == 0] == 1).all(), 'a live environment did not step'
+            assert set(np.unique(dead)) <= {0, 3}, dead
+            hist.append((n, dead, eng.read('N_SOLVES').copy(), eng.read('CHRONIC_ROW').copy()))
+            prev = n
+        runs[mode] = hist
+        stuck = np.array([h[1] == 3 for h in hist])
+        if mode == 1:
+            assert stuck.any(), 'the workload no longer exhausts the restart attempts: pick another one'
+            # ... and every one of them was restarted by a later launch
+            last = stuck.shape[0] - 1 - np.argmax(stuck[::-1], axis=0)
+            for e in np.where(stuck.any(axis=0))[0]:
+                if last[e] < steps - 1:
+                    assert hist[last[e] + 1][1][e] == 0
+        # the explicit call goes on as well
+        for _ in range(20):
+            if not (eng.read('DEAD') == 3).any():
+                break
+            eng.process_game_over()
+        assert not eng.read('DEAD').any()
+        eng.close()
+    for a, b in zip(runs[1], runs[2]):                      # deferred = fused, also through exhausted restarts
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    return int(np.sum([h[1] == 3 for h in runs[1]]))

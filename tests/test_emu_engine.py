@@ -136,3 +136,19 @@ def test_emu_deferred_restart_equals_fused(emu_lib):
 def test_emu_repacked_schedule(emu_lib, solver):
     """Pivots and Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle."""
     assert ec.check_repacked_schedule(emu_lib, steps=6, batch=6, solver=solver) > 0
+
+
+@pytest.mark.parametrize('env,solver,dc', [('default14', 'newton', False), ('default14', 'fdxb', False), ('default14', 'fdxb', True),
+                                           ('default118', 'newton', False)])
+def test_emu_runpf_arrays_solve_boundary(emu_lib, env, solver, dc):
+    seen = ec.check_runpf_arrays(emu_lib, env, 32 if env == 'default118' else 48, solver=solver, dc=dc)
+    assert seen['ok'] >= 16 and seen['split'] and seen['lines_out'] and seen['prods_off'], seen
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_emu_soft_overflow_scenario_k2(emu_lib, solver):
+    ec.check_soft_overflow_scenario(emu_lib, solver)
+
+
+def test_emu_restart_goes_on_after_the_attempt_cap(emu_lib):
+    assert ec.check_restart_goes_on(emu_lib) >= 1

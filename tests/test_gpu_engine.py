@@ -79,6 +79,39 @@ def test_gpu_full_size_default118_4096_bench_workload():
     assert st['done'] > 4096 and st['solves'] > 4096 * 60
 
 
+def test_gpu_full_size_default118_4096_fdxb():
+    """configs[2] with the solver the reference itself runs (PF_ALG = 2, grid.py:63) at the full batch."""
+    st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 30, 10, solver='fdxb', bench_limits=True, max_active_buses=118)
+    assert st['done'] > 2048 and st['solves'] > 4096 * 30
+
+
+def test_gpu_full_size_default118_4096_dc():
+    """rundcpf (grid.py:227-229, loadflow_mode: DC) on IEEE-118 at the full batch, cascade limits."""
+    st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 30, 10, solver='fdxb', bench_limits=True, max_active_buses=118,
+                                     conf={'loadflow_mode': 'DC'})
+    assert st['solves'] > 4096 * 30
+
+
+@pytest.mark.parametrize('env,solver,dc,n', [('default118', 'newton', False, 64), ('default118', 'fdxb', False, 64),
+                                              ('default118', 'fdxb', True, 64), ('default14', 'newton', False, 48),
+                                              ('default30', 'fdxb', False, 48)])
+def test_gpu_runpf_arrays_solve_boundary(env, solver, dc, n):
+    """the reference's seam `runpf(mpc, ppopt, '', '') -> (results, success)` (grid.py:226-229) in MATPOWER
+    arrays with '666'-twin ids -- random states (split nodes, lines out, productions off) vs oracle/pf_np.runpf on the same
+    arrays, <= 1e-8."""
+    seen = ec.check_runpf_arrays(HIP, env, n, solver=solver, dc=dc)
+    assert seen['ok'] >= n // 2 and seen['split'] and seen['lines_out'] and seen['prods_off'], seen
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_soft_overflow_scenario_k2(solver):
+    ec.check_soft_overflow_scenario(HIP, solver)
+
+
+def test_gpu_restart_goes_on_after_the_attempt_cap():
+    assert ec.check_restart_goes_on(HIP, batch=256, steps=12) >= 1
+
+
 def test_gpu_full_size_default14_1024_newton():
     """BASELINE.json configs[1]: default14 (its own chronics: every chronic the fixture carries, start row (37 e) mod T),
     AC Newton-Raphson, 1024 environments, 200 steps against the C oracle."""
