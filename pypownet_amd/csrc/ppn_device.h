@@ -275,7 +275,7 @@ struct Smem {
   // across a solve
   u8 *r2s, *nv, *lf, *lt;             // r2s: bus row -> schedule index (every busbar of the schedule; the live ones are those with touched[row])
   u16 *qrel;
-  double *vc, *ivm, *rhs, *zero;      // vc: V = vc[2i] + j vc[2i+1]; ivm: 1 / |V_i|; zero: {0, 0, 0, 1} = the halves a missing Q row reads as
+  double *vc, *rhs, *zero;            // vc: V = vc[2i] + j vc[2i+1]; zero: {0, 0, 0, 1} = the halves a missing Q row reads as
   // region R
   double* lu;
   double *vm, *va, *psp, *qsp, *mr, *mi;      // bus vectors (view of R)
@@ -328,7 +328,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   { PPN_TAKE8(lf, lb) PPN_TAKE8(lt, lb) }
   o = (o + 15) & ~(size_t)15;
   PPN_TAKE(qrel, u16, NB * 2)
-  PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(ivm, double, NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
+  PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
   const size_t r0 = o;
   S.lu = (double*)(base + r0);
   S.amps = (double*)(base + r0);
