@@ -482,6 +482,21 @@ def main():
             'cpu_baseline': None,
         }
         if world == 1:
+            # OPEN-LOOP rollout (ppn_rollout): the same K steps of the same do-nothing agent in ONE launch -- every environment
+            # plays its K steps back to back instead of waiting, after every step, for the longest cascade of the batch.  Same
+            # results bit for bit (tests: check_rollout_equals_steps); only usable when the actions do not depend on the
+            # observations in between, so it is reported beside the headline, never as `value`
+            eng.sync()
+            r0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+            eng.kernel_time(reset=True)
+            t_r = time.perf_counter()
+            eng.rollout_device(aptr, args.steps, per_step_actions=False, auto_reset=AUTO_RESET)
+            eng.sync()
+            el_r = time.perf_counter() - t_r
+            r1 = int(eng.read('N_STEPS').astype(np.int64).sum())
+            out['config']['open_loop_rollout'] = {
+                'env_steps_per_s': (r1 - r0) / el_r, 'steps_per_launch': args.steps, 'env_steps_executed': r1 - r0,
+                'note': 'ppn_rollout: K steps per environment in one launch (open-loop agents only); not the headline'}
             # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
             # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`
             host_actions = np.zeros((B, case.action_length), dtype=np.uint8)

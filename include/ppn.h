@@ -177,6 +177,8 @@ typedef enum ppn_field {
   PPN_F_SOLVE_OUTCOME,     /* i32 [1]   PPN_SOLVE_*: outcome of the last solve of the last step's cascade                 */
   PPN_F_N_STEPS,           /* i32 [1]   Game.step calls this environment has EXECUTED since ppn_reset: an environment that is over
                                         and waits for its restart does not step (throughput = sum of these / time)         */
+  PPN_F_RETURN,            /* f64 [1]   sum of the five reward components over the steps executed since ppn_reset (PPN_F_N_STEPS
+                                        of them): what a Runner accumulates as cumulative reward (runner.py:120-127)        */
   PPN_F_DEAD,              /* u8 [1]    0 playing; 1 over: the next step skips it until it is restarted; 2 over, its restart is
                                         owed by the next ppn_step(auto_reset = 2) (never seen after ppn_sync); 3 over, and
                                         PPN_RESTART_ATTEMPTS restarts in a row diverged as well (see ppn_process_game_over) */
@@ -235,6 +237,18 @@ int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* c
  * auto_reset = 1 would have shown them. */
 int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
              int32_t auto_reset);
+/* Open-loop rollout: n_steps consecutive Game.step calls of every environment in ONE launch, for callers whose actions do not
+ * depend on the observations in between -- the reference's Runner.loop under a DoNothing agent (pypownet/runner.py:105-131,
+ * agent.py:40-57), a recorded action file replayed (agent.py ActIOnManager), a planned switching sequence being evaluated.
+ * actions: u8 [n_steps x batch x action_len] (per_step_actions = 1: environment b plays actions[s][b] at step s) or
+ * [batch x action_len] (per_step_actions = 0: the same matrix at every step -- only meaningful for the do-nothing action, a
+ * switch replayed every step toggles back and forth).  Same outcome, bit for bit, as n_steps calls of
+ * ppn_step(actions[s], ..., auto_reset): the report fields (PPN_F_DONE, FLAG, REWARD ...) are those of the LAST step,
+ * PPN_F_N_STEPS / PPN_F_RETURN accumulate over all of them.  What differs is the schedule: no environment waits for another
+ * one between its steps, so a launch no longer lasts n_steps times its longest cascade (measurement).
+ * auto_reset as in ppn_step (0: an environment that ends sits out the remaining steps). */
+int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t n_steps,
+                int32_t per_step_actions, int32_t auto_reset);
 /* Topology-action search (the reference's search agents call RunEnv.simulate once per candidate,
  * pypownet/agent.py:161-325): candidate c forks the CURRENT state of environment env_ids[c] and plays
  * Game.simulate(actions[c]) on it (game.py:887-943); any number of candidates per environment, one kernel launch.

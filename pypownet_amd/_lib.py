@@ -61,9 +61,9 @@ FIELDS = ['VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMP
           'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN',
           'SOFT_COUNT', 'DONE', 'FLAG', 'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT',
           'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE', 'REWARD', 'ILLEGAL_COUNTS',
-          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'DEAD']
+          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'RETURN', 'DEAD']
 FIELD_ID = {k: i for i, k in enumerate(FIELDS)}
-_F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD'}
+_F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD', 'RETURN'}
 _U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE',
        'LINE_EVENTS', 'DEAD'}
 
@@ -80,7 +80,7 @@ def field_dtype(name):
 EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limits', 'ppn_load_chronic', 'ppn_reset',
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
-           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays']
+           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays', 'ppn_rollout']
 
 
 def load_library():
@@ -119,6 +119,8 @@ def bind_signatures(lib, full_abi=True):
         lib.ppn_read_observation.restype = C.c_int
         lib.ppn_observation_length.argtypes = [vp, C.c_int32]
         lib.ppn_observation_length.restype = C.c_int32
+        lib.ppn_rollout.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        lib.ppn_rollout.restype = C.c_int
         lib.ppn_runpf_arrays.argtypes = [vp, C.POINTER(PpnMpcBatch)]
         lib.ppn_runpf_arrays.restype = C.c_int
     lib.ppn_set_thermal_limits.argtypes = [vp, C.POINTER(C.c_double)]

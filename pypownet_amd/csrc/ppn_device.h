@@ -248,6 +248,7 @@ struct DevState {
                                    // simulation -- the row the simulation STARTED from (game.py:410-413: simulate does not advance the entries)
   long long* prof;                 // [32] cycle counters per phase (only written by -DPPN_PROF builds)
   double* reward;                  // [5] reward components of the last step
+  double* ret;                     // sum of the reward components over the steps executed since ppn_reset (PPN_F_RETURN)
   int *illn, *actsw;               // [3] illegal-action counts, [2] node / line switches of the action after the step
   float* prio;                     // expected cost of the NEXT step (largest ampere flow / limit after this one): launch order
   // per-environment solve workspace (L2-resident, streamed sequentially by the numeric phases)

@@ -94,6 +94,7 @@ struct ppn_engine {
   std::vector<double> h_br;         // [nl x 5] r, x, b, tap, shift of the case
   std::string err;
   u8* d_actions = nullptr;
+  u8* d_rollout = nullptr; size_t d_rollout_cap = 0;     // action sequence of a ppn_rollout handed over in host memory
   double* d_obs = nullptr;
   u8* d_valid = nullptr;
   int* d_perm = nullptr;            // launch order of the step kernel
@@ -151,8 +152,8 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
-    if (KIND == K_STEP) body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, a.restart_prio, env, 0);
-    else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, env, 0);
+    if (KIND == K_STEP) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
+    else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
     else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, 0);
@@ -318,7 +319,7 @@ static int alloc_state(ppn_engine* e, DevState* s, size_t B) {
   s->prow = dalloc<int>(e, B); s->lev = dalloc<u8>(e, B * d.nl); s->src = dalloc<int>(e, B); s->draws = dalloc<unsigned>(e, B);
   s->prof = dalloc<long long>(e, B * 32);
   s->prio = dalloc<float>(e, B);
-  s->reward = dalloc<double>(e, B * 5); s->illn = dalloc<int>(e, B * 3); s->actsw = dalloc<int>(e, B * 2);
+  s->reward = dalloc<double>(e, B * 5); s->ret = dalloc<double>(e, B); s->illn = dalloc<int>(e, B * 3); s->actsw = dalloc<int>(e, B * 2);
   s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
   s->ws_piv = dalloc<unsigned>(e, B * d.NB);
   s->ws_cache = dalloc<u8>(e, B * (size_t)d.cache_stride);   // zero-filled: header.valid == 0
@@ -376,6 +377,7 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
     case PPN_F_LINE_EVENTS: FI(lev, u8, d.nl, false)
     case PPN_F_SOLVE_OUTCOME: FI(src, int, 1, false)
     case PPN_F_N_STEPS: FI(nstep, int, 1, false)
+    case PPN_F_RETURN: FI(ret, double, 1, false)
     case PPN_F_DEAD: FI(dead, u8, 1, false)
     default: return false;
   }
@@ -854,6 +856,7 @@ static KArgs make_args(ppn_engine* e, bool sim_state) {
   memset(&a, 0, sizeof a);
   a.d = e->dc;
   a.st = sim_state ? e->sim : e->st;
+  a.n_steps = 1;
   return a;
 }
 
@@ -864,6 +867,7 @@ static int settle_restarts(ppn_engine* e) {
   if (!e->pending_restart) return PPN_OK;
   e->pending_restart = false;
   KArgs a = make_args(e, false);
+  a.sim = 1;      // only the owed restarts (PPN_F_DEAD = 2)
   if (launch<K_GAMEOVER>(e, a, e->batch)) return fail(e, PPN_E_HIP, "game-over kernel launch failed: %s", dev_err());
   return PPN_OK;
 }
@@ -1104,21 +1108,33 @@ extern "C" int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p) {
   return PPN_OK;
 }
 
-extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
-                        int32_t auto_reset) {
-  enter(e);
-  if (!e || !actions) return PPN_E_INVALID;
+static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate, int32_t auto_reset,
+                       int n_steps, int per_step_actions) {
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
+  const size_t mat = (size_t)e->batch * e->dc.alen;
   const u8* dact = actions;
   if (!actions_on_device) {
-    if (dev_h2d(e->d_actions, actions, (size_t)e->batch * e->dc.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
-    dact = e->d_actions;
+    const size_t need = per_step_actions ? mat * (size_t)n_steps : mat;
+    if (need > mat) {       // a whole action sequence from the host: staged in a buffer of its own
+      if (need > e->d_rollout_cap) {
+        void* p = nullptr;
+        if (dev_malloc(&p, need)) return fail(e, PPN_E_HIP, "rollout action buffer allocation failed: %s", dev_err());
+        e->allocs.push_back(p);      // (the outgrown buffer is released with the engine)
+        e->d_rollout = (u8*)p; e->d_rollout_cap = need;
+      }
+      if (dev_h2d(e->d_rollout, actions, need, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
+      dact = e->d_rollout;
+    } else {
+      if (dev_h2d(e->d_actions, actions, mat, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
+      dact = e->d_actions;
+    }
   }
   const int mode = simulate ? 0 : (auto_reset == 2 ? 2 : (auto_reset ? 1 : 0));
   if (mode != 2) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (simulate) { if (copy_state(e, &e->sim, &e->st)) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err()); }
   KArgs a = make_args(e, simulate != 0);
   a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = mode;
+  a.n_steps = n_steps; a.action_step_stride = per_step_actions ? mat : 0;
   a.restart_prio = e->restart_prio;
 #ifndef PPN_EMU
   if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first
@@ -1137,6 +1153,25 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
   if (!a.auto_reset && !simulate) e->maybe_dead = true;
   if (mode == 2) e->pending_restart = true;
   return PPN_OK;
+}
+
+extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
+                        int32_t auto_reset) {
+  enter(e);
+  if (!e || !actions) return PPN_E_INVALID;
+  return step_launch(e, actions, actions_on_device, simulate, auto_reset, 1, 0);
+}
+
+extern "C" int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t n_steps,
+                           int32_t per_step_actions, int32_t auto_reset) {
+  enter(e);
+  if (!e || !actions || n_steps <= 0) return PPN_E_INVALID;
+  if (e->maybe_dead && auto_reset) {      // environments that are over right now are restarted first: every environment plays all its steps
+    int rc = ppn_process_game_over(e, nullptr);
+    if (rc) return rc;
+    e->maybe_dead = false;
+  }
+  return step_launch(e, actions, actions_on_device, 0, auto_reset, n_steps, per_step_actions);
 }
 
 // ---- topology-action search: K candidate actions evaluated from the current state of chosen environments --------------

@@ -183,6 +183,25 @@ class Engine(object):
         """actions_ptr: device address of a uint8 [batch x action_len] buffer (e.g. torch_tensor.data_ptr())."""
         self._check(self._lib.ppn_step(self._h, C.c_void_p(int(actions_ptr)), 1, 0, int(auto_reset)), 'ppn_step')
 
+    def rollout(self, actions, n_steps=None, auto_reset=True):
+        """Open-loop rollout (include/ppn.h, ppn_rollout): ``actions`` is ``[n_steps x batch x action_length]`` (one matrix per
+        step) or ``[batch x action_length]`` replayed ``n_steps`` times (the do-nothing agent); one launch, every environment
+        plays its steps back to back."""
+        a = np.asarray(actions)
+        if a.ndim == 3:
+            n_steps = a.shape[0] if n_steps is None else n_steps
+            a = np.ascontiguousarray(a.reshape(n_steps, self.batch, self.case.action_length) != 0, dtype=np.uint8)
+            per_step = 1
+        else:
+            assert n_steps is not None
+            a, per_step = self._actions(a), 0
+        self._check(self._lib.ppn_rollout(self._h, a.ctypes.data, 0, int(n_steps), per_step, int(auto_reset)), 'ppn_rollout')
+
+    def rollout_device(self, actions_ptr, n_steps, per_step_actions=False, auto_reset=True):
+        """The same with the action matrix / sequence already on the device."""
+        self._check(self._lib.ppn_rollout(self._h, C.c_void_p(int(actions_ptr)), 1, int(n_steps), 1 if per_step_actions else 0,
+                                          int(auto_reset)), 'ppn_rollout')
+
     def simulate(self, actions):
         a = self._actions(actions)
         self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 1, 0), 'ppn_step(simulate)')

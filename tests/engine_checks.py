@@ -857,3 +857,61 @@ def check_restart_goes_on(lib_path, batch=16, steps=8):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     return int(np.sum([h[1] == 3 for h in runs[1]]))
+
+
+STATE_FIELDS = ('VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES',
+                'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN', 'SOFT_COUNT', 'DONE', 'FLAG',
+                'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT', 'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'REWARD',
+                'ILLEGAL_COUNTS', 'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'DEAD')
+
+
+def check_rollout_equals_steps(lib_path, envname='default118', batch=24, n_steps=9, bench_limits=True, random_acts=False, seed=5,
+                               modes=(1, 2, 0)):
+    """ppn_rollout (n_steps Game.step calls per environment in one launch, every environment running ahead on its own) leaves
+    every state and report field bit for bit where n_steps calls of ppn_step leave them, and PPN_F_RETURN equals the sum of
+    the per-step rewards."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env(envname, conf={'solver': 'newton'})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    kw = {}
+    if bench_limits:
+        with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
+            kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
+        kw['max_active_buses'] = case.nS
+    rng = np.random.default_rng(seed)
+    slots, t0 = default_assignment(np.arange(batch), chronics)
+    if random_acts:
+        seq = np.stack([random_actions(case, rng, batch, p_node=0.5, p_line=0.4) for _ in range(n_steps)])
+    else:
+        seq = np.zeros((n_steps, batch, case.action_length), dtype=np.uint8)
+    n_done = 0
+    for mode in modes:
+        a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)
+        b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)
+        for e in (a, b):
+            e.reset(chronic_slot=slots, t0=t0)
+            if mode:
+                e.process_game_over()
+        ret = np.zeros(batch)
+        for s in range(n_steps):
+            alive = a.read('DEAD') == 0
+            a.step(seq[s], auto_reset=mode)
+            stepped = alive if mode == 0 else np.ones(batch, dtype=bool)
+            ret += np.where(stepped, a.read('REWARD').sum(axis=1), 0.0)
+            n_done += int(a.read('DONE').sum())
+        if random_acts:
+            b.rollout(seq, auto_reset=mode)
+        else:
+            b.rollout(seq[0], n_steps=n_steps, auto_reset=mode)
+        for f in STATE_FIELDS:
+            x, y = a.read(f), b.read(f)
+            assert np.array_equal(x, y, equal_nan=x.dtype.kind == 'f'), 'auto_reset %d: %s differs after a rollout of %d steps' % (mode, f, n_steps)
+        np.testing.assert_allclose(b.read('RETURN'), ret, rtol=1e-12, atol=1e-9)
+        if mode:
+            assert (b.read('N_STEPS') == n_steps).all()
+        a.close()
+        b.close()
+    return n_done

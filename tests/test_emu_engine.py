@@ -151,4 +151,9 @@ def test_emu_soft_overflow_scenario_k2(emu_lib, solver):
 
 
 def test_emu_restart_goes_on_after_the_attempt_cap(emu_lib):
-    assert ec.check_restart_goes_on(emu_lib) >= 1
+    assert ec.check_restart_goes_on(emu_lib, batch=64, steps=10) >= 1
+
+
+def test_emu_rollout_equals_steps(emu_lib):
+    assert ec.check_rollout_equals_steps(emu_lib, 'default14_for_tests_alpha', batch=12, n_steps=12, bench_limits=False, random_acts=True) > 0
+    assert ec.check_rollout_equals_steps(emu_lib, 'default118', batch=6, n_steps=5, modes=(2,)) >= 0

@@ -112,6 +112,13 @@ def test_gpu_restart_goes_on_after_the_attempt_cap():
     assert ec.check_restart_goes_on(HIP, batch=256, steps=12) >= 1
 
 
+def test_gpu_rollout_equals_steps():
+    """ppn_rollout: n steps per environment in one launch = n ppn_step calls, bit for bit."""
+    assert ec.check_rollout_equals_steps(HIP, 'default118', batch=512, n_steps=12) > 100
+    assert ec.check_rollout_equals_steps(HIP, 'default14_for_tests_alpha', batch=64, n_steps=20, bench_limits=False, random_acts=True) > 0
+    assert ec.check_rollout_equals_steps(HIP, 'default118', batch=64, n_steps=8, bench_limits=False, random_acts=True, modes=(1, 2)) >= 0
+
+
 def test_gpu_full_size_default14_1024_newton():
     """BASELINE.json configs[1]: default14 (its own chronics: every chronic the fixture carries, start row (37 e) mod T),
     AC Newton-Raphson, 1024 environments, 200 steps against the C oracle."""

@@ -28,8 +28,14 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     split = len(sys.argv) > 3 and sys.argv[3] == 'split'     # random node-splitting actions, every busbar may be active
-    case, conf, chronics = bench.load_workload()
-    eng = engine_with_library(lib, case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case),
+    envname = os.environ.get('PPN_PROF_ENV', bench.ENV_NAME)      # e.g. default14: the W = 1 kernels
+    if envname == bench.ENV_NAME:
+        case, conf, chronics = bench.load_workload()
+        limits = bench.bench_limits(case)
+    else:
+        case, conf, chronics = bench.load_env_fixture(envname, os.environ.get('PPN_PROF_SOLVER', 'newton'))
+        limits = None
+    eng = engine_with_library(lib, case, conf, B, chronics=chronics, thermal_limits=limits,
                               max_active_buses=(int(sys.argv[4]) if len(sys.argv) > 4 else 2 * case.nS) if split else case.nS)
     slots, t0 = bench.env_assignment(0, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
