@@ -355,10 +355,6 @@ def main():
     for _ in range(args.warmup):
         eng.step_device(aptr, auto_reset=AUTO_RESET)
     eng.sync()
-    ns0, ni0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
-    nst0 = eng.read('N_STEPS').astype(np.int64).sum()
-    eng.kernel_time(reset=True)
-
     exchange = None
     if args.single_controller and use_dist:
         dev = 'cuda:%d' % local_rank
@@ -390,6 +386,10 @@ def main():
             dist.gather(res.cpu() if on_host else res, gathered, dst=0)      # 24 B per environment back to the controller
         exchange()
 
+    eng.sync()
+    ns0, ni0 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
+    nst0 = eng.read('N_STEPS').astype(np.int64).sum()
+    eng.kernel_time(reset=True)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
