@@ -209,7 +209,7 @@ struct DevCase {
   int nlev;
   int MCAP, TCAP;        // schedule capacities: pivot-neighbour pairs, update triples
   // per-environment schedule cache (global memory): byte offsets of its tables inside one environment's blob
-  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_rowptr, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, co_fill, cache_stride;
+  int co_sig, co_r2s, co_i2r, co_ediag, co_ydiag, co_rowptr, co_le4, co_ly4, co_ymeta, co_lvl, co_tail, co_fill, co_trik, cache_stride;
   // the schedule of the reference topology (every element on busbar 0), shared by all environments: one copy of the
   // tables and records that stays in the L2s instead of `batch` private ones streaming from HBM.  Null until the first
   // ppn_reset has produced it.

@@ -634,7 +634,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     e->rowlen_sub.assign(nS, 0);
     for (int s_ = 0; s_ < nS; ++s_) for (int j = 0; j < nS; ++j) e->rowlen_sub[s_] += filled[pos[s_]][j];
   }
-  if (d.ECAP > 16000) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds 16-bit entry indices"); }
+  if (d.ECAP > 8191) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "LU capacity exceeds the 13-bit diagonal entry of a triple record (8191 pattern entries)"); }
   // Q relocations are 16-bit byte offsets into the storage (qrel = 16 * ECAP + 16 * (first Q entry of the row - row start),
   // 0xFFFF = no Q row): both planes have to end below that
   if (16L * ((long)d.ECAP + d.QCAP) >= 0xFFFFL) { free_all(e); delete e; return fail(nullptr, PPN_E_CAPACITY, "Newton storage (%d + %d half blocks) exceeds the 16-bit Q relocation offsets", d.ECAP, d.QCAP); }
@@ -647,6 +647,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     take(&d.co_ymeta, (size_t)d.YCAP * 4); take(&d.co_lvl, (size_t)(nlev + 1) * 8);
     take(&d.co_tail, 32 + 512);         // dense tail: up to 16 bus indices (+pad), up to 16 x 16 entry map (u16)
     take(&d.co_fill, (size_t)PPN_FILL_REGS * 64 * 4);   // fill-in entries of the pattern (the ones no Ybus entry covers)
+    take(&d.co_trik, (size_t)d.TCAP * 2);               // second word of the triple records (e_kk | TK_* flags, lu_factor)
     d.cache_stride = (int)o;
   }
   d.bus_gs = upload(e, gs, e->allocs); d.bus_bs = upload(e, bs, e->allocs); d.bus_kv = upload(e, kv, e->allocs);
@@ -923,13 +924,15 @@ extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const
 // The SHARED schedule re-packed into fewer rounds of 64 lanes (host side, once per engine; PPN_NO_REBALANCE=1 keeps it as built).
 // (1) Pivots.  The static level of a busbar is the earliest it can be eliminated at; it may be eliminated at any level up to the
 //     one before its first later neighbour's.  Pivots with that slack leave a level whose pair list overflows a multiple of 64
-//     (IEEE-118: level 0 holds 99 pairs -- a second round of phase 1 and of the backward pass for 35 lanes) for later levels
-//     with lanes to spare, the most flexible first; a pivot takes its pair and triple records along.
-// (2) Schur updates.  A triple of pivot k (level L) -- A(i,j) -= A(i,k) U'(k,j) -- may run in the Schur phase of any level from
-//     L up to the level before A(i,j) is first READ (as the pivot block, a pair entry or a triple operand of the earlier of i
-//     and j; by the dense tail), so the records a level holds beyond a multiple of 64 move on the same way.  IEEE-118: 15
-//     rounds of phase 2 per factorisation -> 11.
-// Dependencies are untouched; only the order of the atomic adds into a block (and into a right-hand-side entry) changes.
+//     (IEEE-118: level 0 holds 99 pairs -- a second round of the backward pass for 35 lanes) for later levels with lanes to
+//     spare, the most flexible first; a pivot takes its pair and triple records along.
+// (2) Schur updates.  An OFF-DIAGONAL triple of pivot k (level L) -- A(i,j) -= A(i,k) U'(k,j) -- may run in any level from L up
+//     to the level before A(i,j) is first READ (as the pivot block or a triple operand of the earlier of i and j; by the dense
+//     tail), so the records a level holds beyond a multiple of 64 move on the same way; behind its pivot's level a record finds
+//     U'(k,j) in place (TK_UCOOK).  Diagonal triples carry the stores of their pair (U', forward push, inv(D), y') and stay.
+// A level's list then is [off-diagonal ...][diagonal ...][moved in ...] and the TK_DCOOK flags of the diagonal lanes are set from
+// their final positions (lu_factor).  Dependencies are untouched; only the order of the atomic adds into a block (and into a
+// right-hand-side entry) changes.
 static int rebalance_base_triples(ppn_engine* e) {
   const DevCase& d = e->dc;
   if (getenv("PPN_NO_REBALANCE")) return 0;
@@ -940,7 +943,9 @@ static int rebalance_base_triples(ppn_engine* e) {
   const int ltail = hdr[7];      // levels below the dense tail: records only move among those (the Newton and fast-decoupled factorisations stop there;
                                  // the DC one runs every level, for which the moves are as valid)
   if (n <= 0 || nla <= 1 || n_tri <= 0 || n_pairs <= 0 || ltail <= 1) return 0;
+  if (n > 255 || n_tri > d.TCAP || n_pairs > d.MCAP || nnzF > 8191) return 0;      // (a malformed schedule stays as built)
   unsigned* lvl = (unsigned*)(cache.data() + d.co_lvl);
+  u16* trik = (u16*)(cache.data() + d.co_trik);
   std::vector<unsigned> piv((size_t)n);
   std::vector<u64> pair((size_t)n_pairs), tri((size_t)n_tri);
   if (dev_d2h(piv.data(), e->base_piv, sizeof(unsigned) * (size_t)n, e->stream)) return -1;
@@ -951,15 +956,17 @@ static int rebalance_base_triples(ppn_engine* e) {
   if (Lp[nla] != n || Lm[nla] != n_pairs || Lt[nla] != n_tri) return 0;
   auto rounds = [](int c) { return (c + 63) / 64; };
   const int INF = 1 << 30;
+  struct Tr { u64 r; unsigned kk; };
 
   // ---- (1) pivots ------------------------------------------------------------------------------------------------------
   std::vector<int> lev_of(256, INF), E(256, INF), latest(256, 0), deg(256, 0);
-  std::vector<std::vector<u64>> pairs_of(256), tris_of(256);
+  std::vector<std::vector<u64>> pairs_of(256);
+  std::vector<std::vector<Tr>> tris_of(256);
   std::vector<unsigned> piv_of(256, 0);
   std::vector<int> order_k;               // pivots in list order
   for (int lv = 0; lv < nla; ++lv) for (int q = Lp[lv]; q < Lp[lv + 1]; ++q) { const int k = (int)((piv[q] >> 16) & 0xFFu); lev_of[k] = lv; piv_of[k] = piv[q]; order_k.push_back(k); }
   for (int m = 0; m < n_pairs; ++m) pairs_of[(size_t)(pair[m] >> 56)].push_back(pair[m]);
-  for (int t = 0; t < n_tri; ++t) tris_of[(size_t)(tri[t] >> 56)].push_back(tri[t]);
+  for (int t = 0; t < n_tri; ++t) tris_of[(size_t)(tri[t] >> 56)].push_back(Tr{tri[t], (unsigned)trik[t] & ~(unsigned)(0x4000u | 0x8000u)});
   for (int k : order_k) {
     int first_nb = INF;
     for (u64 r : pairs_of[k]) first_nb = std::min(first_nb, lev_of[(size_t)((r >> 48) & 0xFFu)]);
@@ -992,90 +999,105 @@ static int rebalance_base_triples(ppn_engine* e) {
       int np = 0;
       for (int k : pool[lv]) np += deg[k];
       pr_after += rounds(np);
-      if ((int)pool[lv].size() > 64 && (int)pool[lv].size() > Lp[lv + 1] - Lp[lv]) ok = false;     // (never a second round of pivots)
       if (pool[lv].empty()) ok = false;                                                             // (the level table keeps its shape)
     }
     if (!ok || pr_after >= pr_before) { for (int k : order_k) E[k] = lev_of[k]; pr_after = pr_before; }
-    else {
-      // lists in the new level order (a level: its own pivots in their old order, then the ones that moved in)
-      std::vector<unsigned> piv2; std::vector<u64> pair2, tri2;
-      std::vector<int> Lp2((size_t)nla + 1), Lm2((size_t)nla + 1), Lt2((size_t)nla + 1);
-      for (int lv = 0; lv < nla; ++lv) {
-        Lp2[lv] = (int)piv2.size(); Lm2[lv] = (int)pair2.size(); Lt2[lv] = (int)tri2.size();
-        for (int pass = 0; pass < 2; ++pass)
-          for (int k : order_k) {
-            if (E[k] != lv || (pass == 0) != (lev_of[k] == lv)) continue;
-            piv2.push_back(piv_of[k]);
-            pair2.insert(pair2.end(), pairs_of[k].begin(), pairs_of[k].end());
-            tri2.insert(tri2.end(), tris_of[k].begin(), tris_of[k].end());
-          }
-      }
-      Lp2[nla] = (int)piv2.size(); Lm2[nla] = (int)pair2.size(); Lt2[nla] = (int)tri2.size();
-      if (Lp2[nla] != n || Lm2[nla] != n_pairs || Lt2[nla] != n_tri) return -1;
-      piv.swap(piv2); pair.swap(pair2); tri.swap(tri2); Lp.swap(Lp2); Lm.swap(Lm2); Lt.swap(Lt2);
-    }
   }
+  // pivot and pair lists in the (new) level order: a level's own pivots in their old order, then the ones that moved in
+  std::vector<unsigned> piv2; std::vector<u64> pair2;
+  std::vector<int> Lp2((size_t)nla + 1), Lm2((size_t)nla + 1), Lt2((size_t)nla + 1);
+  std::vector<std::vector<Tr>> offd((size_t)nla), diag((size_t)nla);
+  for (int lv = 0; lv < nla; ++lv) {
+    Lp2[lv] = (int)piv2.size(); Lm2[lv] = (int)pair2.size();
+    for (int pass = 0; pass < 2; ++pass)
+      for (int k : order_k) {
+        if (E[k] != lv || (pass == 0) != (lev_of[k] == lv)) continue;
+        piv2.push_back(piv_of[k]);
+        pair2.insert(pair2.end(), pairs_of[k].begin(), pairs_of[k].end());
+        for (const Tr& t : tris_of[k]) ((t.kk & 0x2000u) ? diag[lv] : offd[lv]).push_back(t);
+      }
+  }
+  Lp2[nla] = (int)piv2.size(); Lm2[nla] = (int)pair2.size();
+  if (Lp2[nla] != n || Lm2[nla] != n_pairs) return -1;
 
   // ---- (2) Schur updates -----------------------------------------------------------------------------------------------
-  std::vector<int> first((size_t)nnzF + 1, INF);      // first level at which a matrix entry is read
+  std::vector<int> first((size_t)nnzF + 1, INF);      // first level at which a matrix entry is read as an operand
   auto rd = [&](unsigned en, int lv) { if (en <= (unsigned)nnzF && lv < first[en]) first[en] = lv; };
   for (int lv = 0; lv < nla; ++lv) {
-    for (int q = Lp[lv]; q < Lp[lv + 1]; ++q) rd(piv[q] & 0xFFFFu, lv);
-    for (int m = Lm[lv]; m < Lm[lv + 1]; ++m) { rd((unsigned)(pair[m] & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 16) & 0xFFFFu), lv); rd((unsigned)((pair[m] >> 32) & 0xFFFFu), lv); }
-    for (int t = Lt[lv]; t < Lt[lv + 1]; ++t) { rd((unsigned)((tri[t] >> 16) & 0xFFFFu), lv); rd((unsigned)((tri[t] >> 32) & 0xFFFFu), lv); }
+    for (int q = Lp2[lv]; q < Lp2[lv + 1]; ++q) rd(piv2[(size_t)q] & 0xFFFFu, lv);
+    for (const std::vector<Tr>* list : {&offd[lv], &diag[lv]})
+      for (const Tr& t : *list) { rd((unsigned)((t.r >> 16) & 0xFFFFu), lv); rd((unsigned)((t.r >> 32) & 0xFFFFu), lv); }
   }
-  struct Rec { u64 r; int last; };      // last level whose Schur phase may hold the record
-  std::vector<std::vector<Rec>> out((size_t)ltail);
+  struct Rec { Tr t; int last; bool cooked; };      // last level that may hold the record; cooked: behind its pivot's level
+  std::vector<std::vector<Rec>> stay((size_t)nla);
   std::vector<Rec> carry;
   long tr_before = 0, tr_after = 0;
-  for (int lv = 0; lv < ltail; ++lv) {
+  for (int lv = 0; lv < nla; ++lv) {
+    const int own = (int)offd[lv].size() + (int)diag[lv].size();
+    if (lv >= ltail) { for (const Tr& t : offd[lv]) stay[lv].push_back(Rec{t, lv, false}); continue; }
     tr_before += rounds(Lt[lv + 1] - Lt[lv]);
     std::vector<Rec> cand = carry;
     carry.clear();
-    for (int t = Lt[lv]; t < Lt[lv + 1]; ++t) {
-      const int fr = first[(size_t)(tri[t] & 0xFFFFu)];
+    for (const Tr& t : offd[lv]) {
+      if ((t.r & 0xFFFFu) > (u64)nnzF) return 0;      // (a record that points outside the pattern: keep the schedule as built)
+      const int fr = first[(size_t)(t.r & 0xFFFFu)];
       int last = (fr < ltail ? fr : ltail) - 1;
       if (last < lv) last = lv;         // (cannot happen: the target of a level's update is read by a later level)
-      cand.push_back(Rec{tri[t], last});
+      cand.push_back(Rec{t, last, false});
     }
-    const int T = (int)cand.size();
+    const int T = (int)cand.size() + (int)diag[lv].size();
     const int x = (lv + 1 < ltail) ? T % 64 : 0;       // records beyond the last full round
     bool moved = false;
-    if (x > 0) {
+    if (x > 0 && T > 64) {
       std::vector<int> idx;
-      for (int c = 0; c < T; ++c) if (cand[c].last > lv) idx.push_back(c);
+      for (int c = 0; c < (int)cand.size(); ++c) if (cand[c].last > lv) idx.push_back(c);
       if ((int)idx.size() >= x) {                      // the x most flexible records move on -- if there are that many that may
         std::stable_sort(idx.begin(), idx.end(), [&](int a_, int b_) { return cand[a_].last > cand[b_].last; });
-        std::vector<char> go((size_t)T, 0);
+        std::vector<char> go(cand.size(), 0);
         for (int c = 0; c < x; ++c) go[idx[c]] = 1;
-        for (int c = 0; c < T; ++c) (go[c] ? carry : out[lv]).push_back(cand[c]);
+        for (int c = 0; c < (int)cand.size(); ++c) { if (go[c]) { Rec r = cand[c]; r.cooked = true; carry.push_back(r); } else stay[lv].push_back(cand[c]); }
         moved = true;
       }
     }
-    if (!moved) {
-      // records that were carried here and cannot wait any longer stay; so does everything else
-      out[lv] = cand;
+    if (!moved) stay[lv] = cand;      // records that were carried here and cannot wait any longer stay; so does everything else
+    tr_after += rounds((int)stay[lv].size() + (int)diag[lv].size());
+    (void)own;
+  }
+  if (!carry.empty()) return 0;       // (cannot happen: `last` never exceeds ltail - 1, where nothing moves on)
+  const bool pivots_moved = pr_after < pr_before;
+  if (!pivots_moved && tr_after >= tr_before) return 0;      // nothing gained: the schedule stays as built
+  // the triple lists: per level [off-diagonal (raw) ...][diagonal ...][moved in (cooked) ...], flags from the final positions
+  std::vector<u64> tri2((size_t)n_tri);
+  std::vector<u16> trik2((size_t)n_tri);
+  int pos = 0;
+  for (int lv = 0; lv < nla; ++lv) {
+    Lt2[lv] = pos;
+    for (const Rec& r : stay[lv]) if (!r.cooked) { tri2[(size_t)pos] = r.t.r; trik2[(size_t)pos] = (u16)r.t.kk; ++pos; }
+    const int d0 = pos;
+    int first_of[256];
+    for (int k = 0; k < 256; ++k) first_of[k] = -1;
+    for (const Tr& t : diag[lv]) {
+      const int k = (int)(t.r >> 56);
+      if (first_of[k] < 0) first_of[k] = pos;
+      unsigned kk = t.kk;
+      if (((pos - Lt2[lv]) >> 6) > ((first_of[k] - Lt2[lv]) >> 6)) kk |= 0x4000u;      // TK_DCOOK
+      tri2[(size_t)pos] = t.r; trik2[(size_t)pos] = (u16)kk; ++pos;
     }
-    tr_after += rounds((int)out[lv].size());
+    (void)d0;
+    for (const Rec& r : stay[lv]) if (r.cooked) { tri2[(size_t)pos] = r.t.r; trik2[(size_t)pos] = (u16)(r.t.kk | 0x4000u | 0x8000u); ++pos; }
   }
-  const bool tri_repacked = carry.empty() && tr_after < tr_before;
-  if (tri_repacked) {
-    int pos = 0;
-    std::vector<u64> tri2 = tri;
-    for (int lv = 0; lv < ltail; ++lv) { Lt[lv] = pos; for (const Rec& r : out[lv]) tri2[(size_t)pos++] = r.r; }
-    if (pos != Lt[ltail]) return -1;      // (the records of the levels of the dense tail and beyond stay where they are)
-    tri.swap(tri2);
-  } else {
-    tr_after = tr_before;
-  }
-  if (pr_after == pr_before && !tri_repacked) return 0;      // nothing gained: the schedule stays as built
+  Lt2[nla] = pos;
+  if (pos != n_tri) return -1;
+  // diagonal triples of ONE pivot must be contiguous in a level's list for the TK_DCOOK rule (they are: tris_of keeps the build order)
   if (getenv("PPN_VERBOSE"))
-    fprintf(stderr, "[ppn] shared schedule: rounds of phase 1 %ld -> %ld, of phase 2 %ld -> %ld\n", pr_before, pr_after, tr_before, tr_after);
-  for (int lv = 0; lv <= nla; ++lv) { lvl[2 * lv] = (unsigned)Lp[lv] | ((unsigned)Lm[lv] << 8); lvl[2 * lv + 1] = (unsigned)Lt[lv]; }
-  if (dev_h2d(e->base_piv, piv.data(), sizeof(unsigned) * (size_t)n, e->stream)) return -1;
-  if (dev_h2d(e->base_pair, pair.data(), sizeof(u64) * (size_t)n_pairs, e->stream)) return -1;
-  if (dev_h2d(e->base_tri, tri.data(), sizeof(u64) * (size_t)n_tri, e->stream)) return -1;
+    fprintf(stderr, "[ppn] shared schedule: rounds of the backward pass %ld -> %ld, of the level passes %ld -> %ld\n", pr_before, pr_after, tr_before, tr_after);
+  for (int lv = 0; lv <= nla; ++lv) { lvl[2 * lv] = (unsigned)Lp2[lv] | ((unsigned)Lm2[lv] << 8); lvl[2 * lv + 1] = (unsigned)Lt2[lv]; }
+  memcpy(trik, trik2.data(), sizeof(u16) * (size_t)n_tri);
+  if (dev_h2d(e->base_piv, piv2.data(), sizeof(unsigned) * (size_t)n, e->stream)) return -1;
+  if (dev_h2d(e->base_pair, pair2.data(), sizeof(u64) * (size_t)n_pairs, e->stream)) return -1;
+  if (dev_h2d(e->base_tri, tri2.data(), sizeof(u64) * (size_t)n_tri, e->stream)) return -1;
   if (dev_h2d(e->base_cache + d.co_lvl, lvl, sizeof(unsigned) * 2 * (size_t)(nla + 1), e->stream)) return -1;
+  if (dev_h2d(e->base_cache + d.co_trik, trik, sizeof(u16) * (size_t)n_tri, e->stream)) return -1;
   return 0;
 }
 
