@@ -176,7 +176,7 @@ def random_node_splitting(case, rng, batch):
 
 
 def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=None, split=False, max_active=None, warmup=4,
-                histogram=False, lu_capacity=0, watch_capacity=0):
+                histogram=False, lu_capacity=0, watch_capacity=0, q_plane_auto=0):
     """One of the other single-GPU configurations of BASELINE.json, timed like the headline (device-resident actions, K steps
     between synchronisations, step-kernel time from HIP events) and priced with its own SURVEY.md 8d byte count."""
     import torch
@@ -187,6 +187,8 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
         kw['max_active_buses'] = max_active
     if lu_capacity:
         kw['lu_capacity'] = lu_capacity
+    if q_plane_auto:
+        kw['q_plane_auto'] = 1
     eng = Engine(case, conf, batch, device=device, chronics=chronics, thermal_limits=limits, **kw)
     slots, t0 = env_assignment(0, batch, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
@@ -229,6 +231,7 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
            'engine_capacity_flags_last_step': int((eng.read('FLAG') == 4).sum())}
     if split:
         out['illegal_fraction_last_step'] = float((eng.read('ILLEGAL') != 0).mean())
+        out['q_plane_auto'] = int(q_plane_auto)
     if watch_capacity:     # untimed: the capacity flag of every environment looked at after every one of some more steps
         raised = 0
         for k in range(watch_capacity):
@@ -264,15 +267,16 @@ def other_configs(device, auto_reset, steps):
     add('configs[2] / configs[3] at 32768 environments on one GPU', ENV_NAME, 'newton', 32768, max(8, steps // 3), device, auto_reset,
         limits=lim, max_active=case118.nS)
     add('configs[4] share of one GPU: default118 AC Newton-Raphson, random node splitting every step, batch 1024, every busbar may '
-        'be active (W = 4 kernels, schedule rebuilt on every accepted switch)', ENV_NAME, 'newton', 1024, steps, device, auto_reset,
-        limits=lim, split=True)
+        'be active (W = 4 kernels, schedule rebuilt on every accepted switch); safe defaults: full Q plane, pattern capacity 2.15 x',
+        ENV_NAME, 'newton', 1024, steps, device, auto_reset, limits=lim, split=True, watch_capacity=20)
     # matrix capacity 1.5 x the base pattern instead of the default 2.15 x (tools/fill_survey.py: the largest pattern over 10^6 random
     # topologies is 1.39 x): the working set drops under 40,960 bytes = 32 LDS granules, four environments per CU instead of three
-    add('configs[4] share of one GPU with rules.lu_capacity = 3976 (pattern capacity 1.5 x base: 4 environments per CU), batch 1024',
-        ENV_NAME, 'newton', 1024, steps, device, auto_reset, limits=lim, split=True, lu_capacity=3976, watch_capacity=20)
+    add('configs[4] share of one GPU with the capacity knobs: rules.lu_capacity = 3976 (pattern capacity 1.5 x base), '
+        'rules.q_plane_auto = 1 (chronic-derived Q plane): 4 environments per CU, batch 1024; capacity flags watched',
+        ENV_NAME, 'newton', 1024, steps, device, auto_reset, limits=lim, split=True, lu_capacity=3976, watch_capacity=20, q_plane_auto=1)
     add('configs[4] workload at a batch that fills the GPU: random node splitting every step, batch 8192 (the whole of configs[4] on '
-        'one GPU), rules.lu_capacity = 3976', ENV_NAME, 'newton', 8192, max(8, steps // 3), device, auto_reset, limits=lim, split=True,
-        lu_capacity=3976, watch_capacity=20)
+        'one GPU), rules.lu_capacity = 3976, rules.q_plane_auto = 1', ENV_NAME, 'newton', 8192, max(8, steps // 3), device, auto_reset,
+        limits=lim, split=True, lu_capacity=3976, watch_capacity=20, q_plane_auto=1)
     add('configs[2] with the limit rule of SURVEY.md 8d config 3: limit = max(50, 1.10 x I(t = 0))', ENV_NAME, 'newton', 4096, steps,
         device, auto_reset, limits=limits_110(case118), max_active=case118.nS, histogram=True)
     return out

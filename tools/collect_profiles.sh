@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel statistics, HBM / SQ counters (separate --pmc passes, as the
 # MI355X guide prescribes), the per-phase cycle profile and the bench line of the current build.  Output: gpurun_out/<tag>/
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -12,7 +12,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace -d $OUT/pmc_sq -o p --output-format csv -- $BENCH > /dev/null 2>&1
 cd $ROOT
-python tools/profile_phases.py 4096 10 > $OUT/phase_profile_b4096.txt 2>&1
+# every kernel of the default bench run (headline + the other configurations: W = 1 and W = 4 step kernels too)
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/stats_all -o bench_all --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_all_under_rocprof.log 2>&1
+cd $ROOT
+PPN_REBUILD=1 python tools/profile_phases.py 4096 10 > $OUT/phase_profile_b4096.txt 2>&1
+PPN_PROF_ENV=default14 python tools/profile_phases.py 1024 20 > $OUT/phase_profile_default14_b1024.txt 2>&1
+PPN_PROF_ENV=default14 python tools/profile_phases.py 16384 10 > $OUT/phase_profile_default14_b16384.txt 2>&1
+python tools/profile_phases.py 1024 8 split > $OUT/phase_profile_split_b1024.txt 2>&1
 python tools/profile_phases.py 32768 4 > $OUT/phase_profile_b32768.txt 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 PPN_LAUNCH_ORDER=0 python bench.py --no-cpu-baseline --no-other-configs > $OUT/bench_no_launch_order.json 2>/dev/null

@@ -29,7 +29,7 @@ def per_launch(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
     src = os.path.join(ROOT, 'gpurun_out', tag)
     dst = os.path.join(ROOT, 'profiles')
     f, nf = per_launch(os.path.join(src, 'pmc_fetch', 'p_counter_collection.csv'))
@@ -50,14 +50,17 @@ def main():
         'sq_per_launch': q,
         'sq_shares_of_wave_cycles': {k: q[k] / q['SQ_WAVE_CYCLES'] for k in ('SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY')},
         'instructions_per_env_step': {k: q[k] / BATCH for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD')},
-        'lds_counters_per_env_step (separate pass, earlier build of this round)':
-            {'SQ_LDS_IDX_ACTIVE': 26461, 'SQ_LDS_BANK_CONFLICT': 11539, 'SQ_LDS_ADDR_CONFLICT': 2117},
     }
     json.dump(out, open(os.path.join(dst, tag + '_pmc_summary.json'), 'w'), indent=1)
     for a, b in (('stats/bench_kernel_stats.csv', '_bench_rocprofv3_kernel_stats.csv'), ('bench.json', '_bench.json'),
                  ('bench_b32768.json', '_bench_b32768.json'), ('bench_no_launch_order.json', '_bench_no_launch_order.json'),
-                 ('phase_profile_b4096.txt', '_phase_profile_b4096.txt'), ('phase_profile_b32768.txt', '_phase_profile_b32768.txt')):
-        shutil.copyfile(os.path.join(src, a), os.path.join(dst, tag + b))
+                 ('phase_profile_b4096.txt', '_phase_profile_b4096.txt'), ('phase_profile_b32768.txt', '_phase_profile_b32768.txt'),
+                 ('stats_all/bench_all_kernel_stats.csv', '_bench_all_configs_rocprofv3_kernel_stats.csv'),
+                 ('phase_profile_default14_b1024.txt', '_phase_profile_default14_b1024.txt'),
+                 ('phase_profile_default14_b16384.txt', '_phase_profile_default14_b16384.txt'),
+                 ('phase_profile_split_b1024.txt', '_phase_profile_split_b1024.txt')):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copyfile(os.path.join(src, a), os.path.join(dst, tag + b))
     # the bench lines were printed before this summary existed: give them the traffic measured on the same build
     for b in ('_bench.json', '_bench_no_launch_order.json'):
         p = os.path.join(dst, tag + b)
