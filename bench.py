@@ -290,6 +290,9 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the side measurements of the other single-GPU configurations')
+    ap.add_argument('--no-rollout', action='store_true',
+                    help='skip the open-loop rollout side figure (profiling passes: its one long launch runs the same kernel symbol as '
+                         'the timed step launches and would skew per-launch averages)')
     ap.add_argument('--single-controller', action='store_true',
                     help="BASELINE.json configs[3]'s exchange variant: every step rank 0 scatters the actions of ALL "
                          'environments and gathers (done, flag, reward) over RCCL; default: policy per GPU, no collective')
@@ -485,7 +488,7 @@ def main():
                                         'pmc_file': (pmc or {}).get('file')}},
             'cpu_baseline': None,
         }
-        if world == 1:
+        if world == 1 and not args.no_rollout:
             # OPEN-LOOP rollout (ppn_rollout): the same K steps of the same do-nothing agent in ONE launch -- every environment
             # plays its K steps back to back instead of waiting, after every step, for the longest cascade of the batch.  Same
             # results bit for bit (tests: check_rollout_equals_steps); only usable when the actions do not depend on the
@@ -501,6 +504,7 @@ def main():
             out['config']['open_loop_rollout'] = {
                 'env_steps_per_s': (r1 - r0) / el_r, 'steps_per_launch': args.steps, 'env_steps_executed': r1 - r0,
                 'note': 'ppn_rollout: K steps per environment in one launch (open-loop agents only); not the headline'}
+        if world == 1:
             # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
             # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`
             host_actions = np.zeros((B, case.action_length), dtype=np.uint8)

@@ -83,16 +83,39 @@ EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limit
            'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays', 'ppn_rollout']
 
 
+def _preload_torch_hip_runtime():
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    if os.environ.get('PPN_IMPORT_TORCH') == '1':
+        import torch  # noqa: F401
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return
+        except OSError:
+            pass
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def load_library():
     """Loads pypownet_amd/libppn.so -- the one and only library of the product path -- and declares its signatures."""
     # PyTorch-ROCm ships its own copy of the HIP runtime.  One process must not end up with two: whichever libamdhip64 is
     # loaded first serves both, and a torch that initialises its device AFTER libppn.so brought in the system runtime finds
-    # "No HIP GPUs".  So when torch is installed it is imported (not initialised) before the engine library.
+    # "No HIP GPUs".  So when torch is installed but not imported yet, ITS runtime library is loaded first -- the shared object
+    # alone, not the framework (importing torch costs seconds and pulls a whole framework into plain RunEnv users);
+    # PPN_IMPORT_TORCH=1 falls back to importing torch itself.
     if 'torch' not in sys.modules:
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'pypownet_amd: the HIP extension %s is missing. Build it with `python __graft_entry__.py` '

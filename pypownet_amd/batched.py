@@ -75,9 +75,9 @@ class BatchedRunEnv(object):
     # torch.from_dlpack -- in which case nothing leaves the GPU: the engine reads the actions where they are
     # (``Engine.step_device``) and writes observations / done / flag / reward into torch CUDA tensors that are returned
     # (``Engine.read_into_device``, ``Engine.observations_into_device``); those export ``__dlpack__`` themselves.
-    @staticmethod
-    def _as_device_tensor(x):
-        """None if x is host data; else a contiguous torch CUDA uint8 tensor viewing (not copying) x."""
+    def _as_device_tensor(self, x):
+        """None if x is host data; else a contiguous torch CUDA uint8 tensor viewing (not copying) x.  The tensor has to live
+        on the engine's GPU: its raw address is handed to the engine."""
         if isinstance(x, np.ndarray) or isinstance(x, (list, tuple)):
             return None
         import torch
@@ -87,6 +87,8 @@ class BatchedRunEnv(object):
             x = torch.from_dlpack(x)
         if not x.is_cuda:
             return None
+        if x.device.index != self.device:
+            raise ValueError('actions live on cuda:%s, this environment batch on cuda:%d' % (x.device.index, self.device))
         if x.dtype != torch.uint8:
             x = (x != 0).to(torch.uint8)
         return x.contiguous()
@@ -106,11 +108,27 @@ class BatchedRunEnv(object):
         e.read_into_device('REWARD', rew.data_ptr(), 8 * rew.numel(), simulation=simulation)
         obs = None
         if want_obs:
-            tdt = torch.float32 if obs_dtype in (np.float32, torch.float32) else torch.float64
+            tdt = torch.float32 if self._is_f32(obs_dtype) else torch.float64
             obs = torch.empty((rows, e.observation_length(layout)), dtype=tdt, device=dev)
             e.observations_into_device(obs.data_ptr(), obs.numel() * obs.element_size(), simulation=simulation, layout=layout,
                                        dtype=np.float32 if tdt == torch.float32 else np.float64)
         return obs, done, flag, ill, rew
+
+    @staticmethod
+    def _is_f32(obs_dtype):
+        """obs_dtype as given by a caller: None (float64), a numpy dtype / its name ('float32'), or a torch dtype."""
+        if obs_dtype is None:
+            return False
+        try:
+            import torch
+            if obs_dtype in (torch.float32, torch.float64):
+                return obs_dtype == torch.float32
+        except ImportError:
+            pass
+        dt = np.dtype(obs_dtype)
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError('obs_dtype must be float32 or float64, got %s' % dt)
+        return dt == np.dtype(np.float32)
 
     def step(self, actions, auto_reset=True, want_obs=True, layout='full', obs_dtype=None):
         """actions: uint8 [batch x action_length] of THIS shard, host array or device tensor (see above).
@@ -122,7 +140,7 @@ class BatchedRunEnv(object):
             done, flag, ill = self.engine.read('DONE'), self.engine.read('FLAG'), self.engine.read('ILLEGAL')
             obs = None
             if want_obs:
-                obs = self.engine.observations(layout=layout, dtype=obs_dtype or np.float64)
+                obs = self.engine.observations(layout=layout, dtype=np.float32 if self._is_f32(obs_dtype) else np.float64)
             return obs, done.astype(bool), flag, ill
         assert tuple(t.shape) == (self.batch, self.action_length)
         self._sync_torch(t)

@@ -152,7 +152,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
-    if (KIND == K_STEP) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
+    if (KIND == K_STEP || KIND == K_ROLLOUT) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
@@ -180,7 +180,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
 // the others only as NT = 0.
 template <int W, int KIND>
 static int launch_nt(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
-  constexpr bool solves = (KIND == K_STEP || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
+  constexpr bool solves = (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
   if (solves && e->newton) return launch_w<W, KIND, solves ? 1 : 0>(e, a, nblocks, timed);
   return launch_w<W, KIND, 0>(e, a, nblocks, timed);
 }
@@ -199,7 +199,7 @@ static int set_lds_attr(size_t bytes) {
   int rc = 0;
 #define PPN_ATTR(K, N) rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
   PPN_ATTR(K_STEP, 0) PPN_ATTR(K_STEP, 1) PPN_ATTR(K_GAMEOVER, 0) PPN_ATTR(K_GAMEOVER, 1) PPN_ATTR(K_RESET, 0) PPN_ATTR(K_RESET, 1)
-  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0)
+  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1)
 #undef PPN_ATTR
   return rc;
 }
@@ -1164,7 +1164,7 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     a.perm = e->d_perm;
   }
 #endif
-  if (launch<K_STEP>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  if (n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, true) : launch<K_STEP>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   if (a.auto_reset && e->maybe_dead) {
     // environments that were already over when the step began (after ppn_reset or after steps without auto_reset) did
     // not step; they are restarted by this post-pass.  Environments that end DURING a step restart inside the step

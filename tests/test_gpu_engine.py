@@ -320,3 +320,28 @@ def test_gpu_bench_two_ranks_share_one_gpu(single_controller, tmp_path):
     assert d['config']['env_assignment_crc32'] == want
     # the aggregate: both ranks' environments over the slowest rank's time
     assert abs(d['value'] - 2 * B * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']
+
+
+def test_gpu_engine_library_first_then_torch():
+    """One HIP runtime per process: loading libppn.so BEFORE torch is imported (pypownet_amd/_lib.py preloads the runtime torch
+    bundles, not the framework) must leave torch able to see the GPU, and both must work side by side."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from pypownet_amd import _lib\n"
+        "_lib.load_library()\n"
+        "assert 'torch' not in sys.modules\n"
+        "from helpers import load_env\n"
+        "from pypownet_amd.engine import Engine\n"
+        "case, cfg, chronics = load_env('default14_for_tests')\n"
+        "eng = Engine(case, cfg, 4, chronics=chronics)\n"
+        "eng.reset(); eng.step(np.zeros((4, case.action_length), dtype=np.uint8))\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "t = torch.ones(8, device='cuda') * 2\n"
+        "assert float(t.sum()) == 16.0 and not eng.read('DONE').any()\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, 'tests'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]

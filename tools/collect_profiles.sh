@@ -6,7 +6,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-rollout"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- $BENCH > /dev/null 2>&1
@@ -14,7 +14,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 cd $ROOT
 # every kernel of the default bench run (headline + the other configurations: W = 1 and W = 4 step kernels too)
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats_all -o bench_all --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_all_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats_all -o bench_all --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-rollout > $OUT/bench_all_under_rocprof.log 2>&1
 cd $ROOT
 PPN_REBUILD=1 python tools/profile_phases.py 4096 10 > $OUT/phase_profile_b4096.txt 2>&1
 PPN_PROF_ENV=default14 python tools/profile_phases.py 1024 20 > $OUT/phase_profile_default14_b1024.txt 2>&1
