@@ -288,6 +288,26 @@ def test_gpu_batched_tensor_api():
     assert np.array_equal(o1, o2.cpu().numpy(), equal_nan=True)
 
 
+def test_gpu_bench_spawns_its_ranks_when_launched_bare():
+    """`python bench.py --gpus 2` without a launcher (how a driver may call it): bench.py spawns the two ranks itself and the line
+    says n_gpus = 2; asking for more ranks than GPUs under RCCL is a non-zero exit, not a one-rank run."""
+    import json
+    import subprocess
+    import sys
+    B = 128
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', str(B),
+           '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run(cmd, env=dict(env, PPN_BENCH_BACKEND='gloo'), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['config']['env_steps_executed'] == 2 * B * 3
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)      # RCCL: one GPU per rank
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith('{')]
+
+
 @pytest.mark.parametrize('single_controller', [False, True])
 def test_gpu_bench_two_ranks_share_one_gpu(single_controller, tmp_path):
     """The N > 1 path of bench.py end to end: two ranks (PPN_BENCH_BACKEND=gloo lets them share this box's one GPU; on the
