@@ -239,6 +239,14 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
             raised += int((eng.read('FLAG') == 4).sum())
         out['lu_capacity'] = lu_capacity
         out['engine_capacity_flags_in_%d_watched_steps' % watch_capacity] = raised
+    if not split and not histogram:
+        # the same K steps as ONE open-loop launch (ppn_rollout; do-nothing actions only): beside the stepped rate, never instead
+        eng.sync()
+        r0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+        t = time.perf_counter()
+        eng.rollout_device(acts[0].data_ptr(), steps, per_step_actions=False, auto_reset=auto_reset)
+        eng.sync()
+        out['open_loop_rollout_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - r0) / (time.perf_counter() - t)
     if histogram:
         out['note'] = 'DONE / CASCADE_DEPTH read back every step for the statistics: the rate includes that synchronisation'
         out['game_over_rate'] = n_done / float(max(executed, 1))
