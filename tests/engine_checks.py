@@ -372,7 +372,7 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
         stats['illegal'] += int((orc.read('ILLEGAL')[k] != 0).sum())
         stats['split_buses'] = max(stats['split_buses'], int((bt[:, case.nS:] != 4).sum(axis=1).max()))
     stats['dropped'] = int((~tracked).sum())
-    assert stats['dropped'] <= (max(2, batch // 10) if max_dropped is None else max_dropped), 'too many environments dropped as degenerate: %d' % stats['dropped']
+    assert stats['dropped'] <= (max(2, batch // 16) if max_dropped is None else max_dropped), 'too many environments dropped as degenerate: %d' % stats['dropped']
     return stats
 
 
@@ -524,7 +524,7 @@ def check_random_chronic_looping(lib_path, envname='default14', steps=30, batch=
     must come up, and the draws must be reproducible under the seed and different under another one."""
     cf = {'solver': 'newton'}
     st = check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, 'newton', seed=seed, conf=cf,
-                                          max_dropped=max(2, batch // 10), game_over_mode='hard', looping_mode='random',
+                                          max_dropped=max(2, batch // 12), game_over_mode='hard', looping_mode='random',
                                           rng_seed=20260928)
     assert st['done'] > batch // 4, st
     seqs = []

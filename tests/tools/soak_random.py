@@ -21,7 +21,7 @@ def main():
     lib = os.path.join(ROOT, 'pypownet_amd', 'libppn.so')
     tot = dict(done=0, illegal=0, split_buses=0, dropped=0, excused=0, rejoined=0)
     for c in range(chunks):
-        st = ec.check_random_actions_vs_c_oracle(lib, env, steps, batch, solver, seed=1000 + 17 * c, max_dropped=batch // 10)
+        st = ec.check_random_actions_vs_c_oracle(lib, env, steps, batch, solver, seed=1000 + 17 * c, max_dropped=batch // 16)
         for k in tot:
             tot[k] = max(tot[k], st[k]) if k == 'split_buses' else tot[k] + st[k]
         print('chunk %d: %s' % (c, st), flush=True)
