@@ -291,3 +291,68 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
                     np.testing.assert_allclose(eng.observations()[0], z['obs_after'][k], rtol=0, atol=TOL_ENGINE_FLOW)
     eng.close()
     return counts
+
+
+# ---- (c) the drop-in API: pypownet_amd.environment.RunEnv on an engine library -------------------------------------------
+def replay_runenv(lib_path, name, max_steps=None):
+    """The recorded run through the product's ``RunEnv`` (one environment, the reference's own call pattern:
+    ``obs, reward, done, flag = env.step(action, do_sum=False)``, ``env.process_game_over()`` after a game over): the returned
+    tuple must be the reference's -- observation array, the five-component reward list (the shipped CustomRewardSignal,
+    restated in pypownet_amd.reward_signal), done, the exception CLASS and the masks an IllegalActionException carries."""
+    import harness
+    from pypownet_amd import environment as penv
+    from pypownet_amd.reward_signal import DefaultGridRewardSignal
+    run = Run(name)
+    assert run.limits is None, 'RunEnv takes its thermal limits from the chronics, like the reference'
+    z = run.z
+    overrides = dict(run.meta['conf'])
+    overrides['solver'] = run.meta['solver']
+    classes = {0: type(None), 1: penv.DivergingLoadflowException, 2: penv.TooManyConsumptionsCut, 3: penv.TooManyProductionsCut,
+               4: penv.IllegalActionException}
+    counts = dict(steps=0, done=0, illegal=0, obs=0, islands=0)
+    with harness.library(lib_path):
+        env = penv.RunEnv(os.path.join(ROOT, 'tests', 'golden', 'envs', run.meta['fixture_env']), 'level0',
+                          game_over_mode=run.meta['game_over_mode'], config_overrides=overrides)
+        env.reward_signal = DefaultGridRewardSignal(run.case.nS)
+        np.testing.assert_allclose(env.get_observation(), z['init_obs'], rtol=0, atol=TOL_ENGINE_FLOW)
+        for t in range(run.steps if max_steps is None else min(run.steps, max_steps)):
+            where = '%s at step %d' % (name, t)
+            action = env.action_space.array_to_action(run.actions[t].astype(int))
+            obs, reward, done, flag = env.step(action, do_sum=False)
+            want = int(z['flag'][t])
+            if isinstance(flag, penv.DivergingLoadflowException) and want != 1 and 'not connexe' in flag.text \
+                    and island_without_reference(run, t):
+                counts['islands'] += 1                       # (see island_without_reference)
+                if not z['done'][t]:
+                    break
+                env.process_game_over()
+                continue
+            assert bool(done) == bool(z['done'][t]), where
+            assert type(flag) is classes[want], '%s: %r, the reference returned class %d' % (where, flag, want)
+            if want == FLAG_ILLEGAL:
+                assert bool(flag.get_has_too_much_activations()) == bool(z['ill_too_many'][t]), where
+                for got, key in ((flag.get_illegal_broken_lines_reconnections(), 'ill_broken'),
+                                 (flag.get_illegal_oncoolown_lines_switches(), 'ill_line_cd'),
+                                 (flag.get_illegal_oncoolown_substations_switches(), 'ill_node_cd')):
+                    assert (got is None) == (not z[key][t].any()), '%s: %s' % (where, key)       # the reference hands out None for an empty mask
+                    if got is not None:
+                        assert np.array_equal(np.asarray(got, dtype=bool), z[key][t]), '%s: %s' % (where, key)
+                counts['illegal'] += 1
+                # the Action object was repaired in place (game.py:809-846)
+                assert np.array_equal(np.asarray(env.game.last_action.as_array()).astype(int), run.repaired_action(t)), where
+            assert (obs is None) == bool(z['done'][t]), where
+            if not np.isnan(z['reward'][t]).any():
+                np.testing.assert_allclose(reward, z['reward'][t], rtol=1e-7, atol=1e-6, err_msg=where)
+            if obs is not None and t in run.sampled:
+                np.testing.assert_allclose(obs, z['obs'][run.sampled[t]], rtol=0, atol=TOL_ENGINE_FLOW, err_msg=where)
+                o = env.observation_space.array_to_observation(obs)
+                assert np.array_equal(o.lines_status.astype(int), z['step_line_status'][t].astype(int))
+                counts['obs'] += 1
+            counts['steps'] += 1
+            if done:
+                counts['done'] += 1
+                after = env.process_game_over()
+                if t in run.ended_sampled:
+                    np.testing.assert_allclose(after, z['obs_after'][run.ended_sampled[t]], rtol=0, atol=TOL_ENGINE_FLOW, err_msg=where)
+        env.game.engine.close()
+    return counts

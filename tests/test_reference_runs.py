@@ -56,3 +56,22 @@ def test_gpu_replays_reference_run(name):
     c = rr.replay_engine(None, name, batch=3)
     _check_counts(name, c)
     assert c['obs'] >= 10, (name, c)
+
+
+RUNENV_NAMES = [n for n in ('default14_soft', 'alpha14_hard', 'default14_dc_soft', 'default14_newton_soft', 'default30_hard',
+                            'default118_soft', 'default118_hard') if n in NAMES]
+
+
+@pytest.mark.parametrize('name', RUNENV_NAMES)
+def test_runenv_on_emulation_build_replays_reference_run(emu_lib, name):
+    """The drop-in API itself (pypownet_amd.environment.RunEnv: tuple of step(), exception classes and masks, reward list,
+    process_game_over) against what the reference's RunEnv returned."""
+    c = rr.replay_runenv(emu_lib, name, max_steps=150)
+    assert c['steps'] >= 130 and c['done'] >= 10 and c['islands'] <= 2, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', RUNENV_NAMES)
+def test_gpu_runenv_replays_reference_run(name):
+    c = rr.replay_runenv(None, name)
+    assert c['steps'] >= 0.9 * rr.Run(name).steps - 1 and c['islands'] <= 2, c
