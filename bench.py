@@ -47,6 +47,10 @@ def load_workload():
     conf['solver'] = 'newton'
     cdir = os.path.join(d, 'chronics')
     chronics = [Chronic(os.path.join(cdir, c)) for c in sorted(os.listdir(cdir))]
+    # (PPN_BENCH_CHRONICS=2: the two-chronic mix round 2 was measured on -- comparisons across rounds only)
+    n_keep = int(os.environ.get('PPN_BENCH_CHRONICS', '0'))
+    if n_keep > 0:
+        chronics = chronics[:n_keep]
     return case, conf, chronics
 
 
