@@ -25,7 +25,41 @@ __global__ void k_tail(const double* A, const double* b, double* x, int rows, un
   if (lane0 < rows) x[(size_t)sys * M + lane0] = ty;
 }
 
+// timing: the same elimination + substitution 64 times back to back on one wave (results chained through ty)
+__global__ void k_tail_time(const double* A, const double* b, double* x, long long* clk, int rows, unsigned idrows) {
+  const int lane0 = threadIdx.x;
+  double a0[M]; double ty, tinv = 1.0, y0;
+  for (int j = 0; j < M; ++j) a0[j] = (lane0 < rows && j < rows) ? A[(size_t)lane0 * M + j] : 0.0;
+  y0 = lane0 < rows ? b[lane0] : 0.0;
+  ty = y0;
+  const long long t0 = clock64();
+  for (int rep = 0; rep < 64; ++rep) {
+    double ta[M];
+    for (int j = 0; j < M; ++j) ta[j] = a0[j] + 1e-300 * ty;
+    ty = y0 + 1e-300 * ty;
+    tinv = 1.0;
+    tail_eliminate<0, M>(ta, ty, tinv, rows, idrows, lane0);
+    tail_substitute<M - 1, M>(ta, ty, tinv, rows, idrows, lane0);
+  }
+  const long long t1 = clock64();
+  if (lane0 < rows) x[lane0] = ty;
+  if (lane0 == 0) clk[0] = (t1 - t0) / 64;
+}
+
 int main() {
+  {
+    std::vector<double> A((size_t)M * M, 0.0), b(M, 0.3);
+    for (int i = 0; i < M; ++i) for (int j = 0; j < M; ++j) A[(size_t)i * M + j] = (i == j) ? M + 1.0 : 0.25 + 0.01 * ((i * 7 + j * 3) % 5);
+    double *dA, *db, *dx; long long* dc; long long c = 0;
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&db, b.size() * 8); hipMalloc(&dx, M * 8); hipMalloc(&dc, 8);
+    hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice);
+    for (int rows = M; rows >= M - 2; rows -= 2) for (unsigned idr : {0u, 0x2u | 0x80u}) {
+      hipLaunchKernelGGL(k_tail_time, dim3(1), dim3(64), 0, 0, dA, db, dx, dc, rows, idr);
+      hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+      printf("timing: M %d rows %2d identity rows 0x%04x: %lld clocks per elimination + substitution\n", M, rows, idr, c);
+    }
+    hipFree(dA); hipFree(db); hipFree(dx); hipFree(dc);
+  }
   const int NS = 64;
   int bad = 0;
   for (int rows = 2; rows <= M; rows += 2) {
