@@ -155,6 +155,26 @@ class BatchedRunEnv(object):
         import torch
         torch.cuda.current_stream(t.device).synchronize()
 
+    def rollout(self, actions, n_steps=None, auto_reset=True):
+        """Open-loop rollout (include/ppn.h, ppn_rollout): ``actions`` uint8 ``[n_steps x batch x action_length]`` (one matrix per
+        step) or ``[batch x action_length]`` replayed ``n_steps`` times (the do-nothing agent of the reference's Runner), host
+        array or device tensor; every environment plays its steps back to back in ONE launch.  Returns (cumulative reward since
+        reset [batch], done / flag of the LAST step, steps executed since reset [batch])."""
+        t = self._as_device_tensor(actions)
+        e = self.engine
+        if t is None:
+            e.rollout(actions, n_steps=n_steps, auto_reset=auto_reset)
+        else:
+            per_step = t.dim() == 3
+            if per_step:
+                n_steps = t.shape[0] if n_steps is None else n_steps
+                assert tuple(t.shape[1:]) == (self.batch, self.action_length)
+            else:
+                assert n_steps is not None and tuple(t.shape) == (self.batch, self.action_length)
+            self._sync_torch(t)
+            e.rollout_device(t.data_ptr(), n_steps, per_step_actions=per_step, auto_reset=auto_reset)
+        return e.read('RETURN'), e.read('DONE').astype(bool), e.read('FLAG'), e.read('N_STEPS')
+
     def search(self, candidate_actions, want_obs=False):
         """Topology-action search (what the reference's search agents do with one ``simulate`` call per candidate,
         pypownet/agent.py:161-325): ``candidate_actions`` uint8 [batch x K x action_length], host array or device tensor; every

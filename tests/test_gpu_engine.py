@@ -286,6 +286,19 @@ def test_gpu_batched_tensor_api():
     assert r2.is_cuda and np.array_equal(f1, f2.cpu().numpy()) and np.array_equal(d1, d2.cpu().numpy())
     np.testing.assert_allclose(r1, r2.cpu().numpy(), rtol=1e-13, atol=1e-13)      # (sums of the 5 components in another order)
     assert np.array_equal(o1, o2.cpu().numpy(), equal_nan=True)
+    # open-loop rollout: a recorded action sequence from host memory and from a device tensor, against the stepped path
+    seq = np.stack([ec.random_actions(case, rng, B) for _ in range(6)])
+    ret0 = host.engine.read('RETURN').copy()
+    for k in range(6):
+        host.step(seq[k], auto_reset=True, want_obs=False)
+    r_h = host.engine.read('RETURN') - ret0
+    ret0 = dev.engine.read('RETURN').copy()
+    ret, done, flag, nst = dev.rollout(torch.from_numpy(seq).cuda(), auto_reset=True)
+    np.testing.assert_allclose(ret - ret0, r_h, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(done, host.engine.read('DONE').astype(bool)) and np.array_equal(flag, host.engine.read('FLAG'))
+    assert np.array_equal(dev.engine.read('VM'), host.engine.read('VM'), equal_nan=True)
+    with pytest.raises(ValueError):
+        dev.step(torch.zeros((B, case.action_length), dtype=torch.uint8, device='cuda:0'), obs_dtype='int32')
 
 
 def test_gpu_bench_spawns_its_ranks_when_launched_bare():
