@@ -41,6 +41,13 @@ class Run(object):
         self.case, self.conf, self.chronics = load_env(self.meta['fixture_env'], conf=conf)
         assert [c.name for c in self.chronics] == self.meta['chronics'], 'fixture environment holds another chronic set'
         self.limits = self.z.get('thermal_limits')
+        # Game.simulate calls recorded before some steps (scenarios '*_simulate_*'): step -> index
+        self.sims = {}
+        if 'sim_step' in self.z:
+            self.sim_actions = np.unpackbits(self.z['sim_action'], axis=1)[:, :n]
+            self.sim_actions_after = np.unpackbits(self.z['sim_action_after'], axis=1)[:, :n]
+            self.sims = {int(t): k for k, t in enumerate(self.z['sim_step'])}
+            self.sim_obs = {int(k): j for j, k in enumerate(self.z['sim_obs_index'])}
 
     def oracle_game(self):
         return OracleGame(self.case, self.conf, self.chronics, game_over_mode=self.meta['game_over_mode'],
@@ -100,6 +107,47 @@ def expected_reward(run, t, n_loads_cut, n_prods_cut, topo_bits, amps, limits, c
                                     n_loads_cut, n_prods_cut, topo_bits, amps, limits)
 
 
+def _sim_expected_reward(run, k, n_loads_cut, n_prods_cut, topo_bits, amps, limits):
+    z = run.z
+    flag = int(z['sim_flag'][k])
+    counts = tuple(int(v) for v in z['sim_ill_counts'][k])
+    bits = 0
+    if flag == FLAG_ILLEGAL:
+        bits = (1 if z['sim_ill_too_many'][k] else 0) | (2 if counts[0] else 0) | (4 if counts[1] else 0) | (8 if counts[2] else 0)
+    a = run.sim_actions_after[k].astype(np.int64)
+    c = run.case
+    o = c.nP + c.nL + 2 * c.nl
+    kf = reward_np.coefficients(c.nS)
+    return reward_np.compute_reward(kf, flag if flag != FLAG_ILLEGAL else 0, bits, counts, int(a[:o].sum()), int(a[o:].sum()),
+                                    n_loads_cut, n_prods_cut, topo_bits, amps, limits)
+
+
+def _check_oracle_simulate(run, g, k, where):
+    """Game.simulate (game.py:887-943) before the step: result against the recording, and nothing may have moved."""
+    z = run.z
+    import copy
+    snap = {f: copy.deepcopy(getattr(g, f)) for f in g._SNAP}
+    obs, flag, bits, done = g.simulate(run.sim_actions[k].astype(np.int64).copy())
+    want = int(z['sim_flag'][k])
+    assert bool(done) == bool(z['sim_done'][k]), '%s: simulated done differs %s' % (run.name, where)
+    if want == FLAG_ILLEGAL:
+        assert flag == 0 and bits != 0 and bool(bits & 1) == bool(z['sim_ill_too_many'][k]), '%s: simulated illegal action %s' % (run.name, where)
+    else:
+        assert flag == want, '%s: simulated flag %d vs %d %s' % (run.name, flag, want, where)
+    if k in run.sim_obs and not done:
+        np.testing.assert_allclose(obs_as_array(obs), z['sim_obs'][run.sim_obs[k]], rtol=0, atol=TOL_OBS,
+                                   err_msg='%s simulated observation %s' % (run.name, where))
+    if not done and not np.isnan(z['sim_reward'][k]).any():
+        topo = np.concatenate([obs['productions_nodes'], obs['loads_nodes'], obs['lines_or_nodes'], obs['lines_ex_nodes']])
+        exp = _sim_expected_reward(run, k, int(np.sum(obs['are_loads_cut'])), int(np.sum(obs['are_productions_cut'])), topo,
+                                   obs['ampere_flows'], obs['thermal_limits'])
+        np.testing.assert_allclose(exp, z['sim_reward'][k], rtol=1e-9, atol=1e-9, err_msg='%s simulated reward %s' % (run.name, where))
+    for f, v in snap.items():
+        assert np.array_equal(np.asarray(getattr(g, f), dtype=object) if False else getattr(g, f), v) if not isinstance(v, np.ndarray) \
+            else np.array_equal(getattr(g, f), v, equal_nan=True), '%s: simulate left a trace in %s %s' % (run.name, f, where)
+    return 1
+
+
 def replay_oracle(name):
     run = Run(name)
     z = run.z
@@ -110,6 +158,8 @@ def replay_oracle(name):
     counts = dict(done=0, illegal=0, obs=0, restarts=0)
     for t in range(run.steps):
         where = 'at step %d' % t
+        if t in run.sims:
+            counts['sims'] = counts.get('sims', 0) + _check_oracle_simulate(run, g, run.sims[t], where)
         before = (g.reconnectable.copy(), g.line_cooldown.copy(), g.node_cooldown.copy())
         obs, flag, bits, done = g.step(run.actions[t].astype(np.int64).copy())
         assert bool(done) == bool(z['done'][t]), '%s: done differs %s' % (name, where)
@@ -238,6 +288,31 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
     counts = dict(done=0, illegal=0, obs=0, islands=0, steps=0)
     for t in range(run.steps):
         where = 'at step %d' % t
+        if t in run.sims:
+            k = run.sims[t]
+            before = {f: eng.read(f).copy() for f in ('VM', 'LINES_STATUS', 'RECONNECTABLE', 'SOFT_COUNT', 'CHRONIC_ROW', 'PRODS_NODES')}
+            eng.simulate(np.repeat(run.sim_actions[k][None, :], batch, axis=0))
+            sd, sf, sb = eng.read('DONE', simulation=True), eng.read('FLAG', simulation=True), eng.read('ILLEGAL', simulation=True)
+            want = int(z['sim_flag'][k])
+            skip = int(sf[0]) == 1 and want != 1 and int(eng.read('SOLVE_OUTCOME', simulation=True)[0]) == 2      # (island: see below)
+            if not skip:
+                for b in range(batch):
+                    assert bool(sd[b]) == bool(z['sim_done'][k]), '%s: simulated done differs %s' % (name, where)
+                    if want == FLAG_ILLEGAL:
+                        assert int(sf[b]) == 0 and int(sb[b]) != 0 and bool(int(sb[b]) & 1) == bool(z['sim_ill_too_many'][k])
+                        if not int(sb[b]) & 1:
+                            assert list(eng.read('ILLEGAL_COUNTS', simulation=True)[b][:3]) == [int(v) for v in z['sim_ill_counts'][k]]
+                    else:
+                        assert int(sf[b]) == want, '%s: simulated flag %d vs %d %s' % (name, sf[b], want, where)
+                if check_obs and k in run.sim_obs and not z['sim_done'][k]:
+                    np.testing.assert_allclose(eng.observations(simulation=True)[0], z['sim_obs'][run.sim_obs[k]], rtol=0, atol=TOL_ENGINE_FLOW,
+                                               err_msg='%s simulated observation %s' % (name, where))
+                if check_reward and not np.isnan(z['sim_reward'][k]).any():
+                    np.testing.assert_allclose(eng.read('REWARD', simulation=True)[0], z['sim_reward'][k], rtol=1e-7, atol=1e-6,
+                                               err_msg='%s simulated reward %s' % (name, where))
+                counts['sims'] = counts.get('sims', 0) + 1
+            for f, v in before.items():          # Game.simulate leaves no trace (K10)
+                assert np.array_equal(eng.read(f), v, equal_nan=True), '%s: simulate left a trace in %s %s' % (name, f, where)
         eng.step(np.repeat(run.actions[t][None, :], batch, axis=0), auto_reset=False)
         done, flag, bits = eng.read('DONE'), eng.read('FLAG'), eng.read('ILLEGAL')
         want_flag = int(z['flag'][t])

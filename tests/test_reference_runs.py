@@ -20,7 +20,7 @@ NAMES = rr.scenario_names()
 
 
 def test_fixture_set_is_complete():
-    assert len(NAMES) >= 16
+    assert len(NAMES) >= 19
     envs = {rr.Run(n).meta['fixture_env'] for n in NAMES}
     assert {'default14', 'default30', 'default118'} <= envs
     modes = {(rr.Run(n).meta['fixture_env'], rr.Run(n).meta['game_over_mode']) for n in NAMES}
@@ -30,7 +30,9 @@ def test_fixture_set_is_complete():
 @pytest.mark.parametrize('name', NAMES)
 def test_numpy_oracle_replays_reference_run(name):
     c = rr.replay_oracle(name)
-    assert c['done'] >= 20 and c['obs'] >= 15, c
+    assert c['done'] >= 20 and c['obs'] >= 10, c
+    if 'simulate' in name:
+        assert c['sims'] >= 40, c
 
 
 def _check_counts(name, c):
@@ -38,6 +40,8 @@ def _check_counts(name, c):
     # at most a couple of islanded solves set aside, and the bulk of the run replayed
     assert c['islands'] <= 2 and c['steps'] >= 0.9 * run.steps - 1, (name, c)
     assert c['done'] >= 15, (name, c)
+    if 'simulate' in name:
+        assert c.get('sims', 0) >= 40, (name, c)
 
 
 @pytest.mark.parametrize('name', NAMES)

@@ -75,6 +75,14 @@ SCENARIOS = {
                                          seed=36, limits='limits_a', solver='newton', mix='wild'),
     'default118_dc_soft':    dict(env='parameters/default118', fixture_env='default118', mode='soft', steps=200, seed=37,
                                   limits='limits_a', conf={'loadflow_mode': 'DC'}),
+    # Game.simulate (game.py:887-943) interleaved with the steps: a candidate action is simulated before about every third step
+    # (planned injections of the CURRENT entry, no hazards, nothing may leak into the game) and its result recorded as well
+    'default14_simulate_soft':  dict(env='parameters/default14', fixture_env='default14', mode='soft', steps=250, seed=41,
+                                     simulate=True),
+    'default30_simulate_hard':  dict(env='parameters/default30', fixture_env='default30', mode='hard', steps=200, seed=42,
+                                     simulate=True),
+    'default118_simulate_soft': dict(env='parameters/default118', fixture_env='default118', mode='soft', steps=150, seed=43,
+                                     limits='limits_a', solver='newton', simulate=True),
 }
 
 
@@ -306,10 +314,7 @@ def run_scenario(name):
     initial_obs = env.get_observation()
     nl, ns = game.grid.n_lines, len(game.substations_ids)
     recent = dict(subs=[], lines=[])
-    for step in range(spec['steps']):
-        action = draw_action(rng, env, step, spec.get('mix', 'gentle'), recent)
-        submitted = np.asarray(action.as_array(), dtype=np.uint8).copy()     # BEFORE step: the repair edits the object
-        obs, reward, done, flag = env.step(action, do_sum=False)
+    def classify(flag):
         code, too_many = FLAG_NONE, False
         broken, line_cd, node_cd = np.zeros(nl, bool), np.zeros(nl, bool), np.zeros(ns, bool)
         if isinstance(flag, renv.DivergingLoadflowException):
@@ -328,6 +333,26 @@ def run_scenario(name):
                     dst[:] = np.asarray(src, dtype=bool)
         else:
             assert flag is None, flag
+        return code, too_many, broken, line_cd, node_cd
+
+    sim = dict(step=[], action=[], action_after=[], done=[], flag=[], ill_too_many=[], ill_counts=[], reward=[], obs=[])
+    for step in range(spec['steps']):
+        if spec.get('simulate') and rng.rand() < 0.35:
+            cand = draw_action(rng, env, step, 'gentle', dict(subs=list(recent['subs']), lines=list(recent['lines'])))
+            cand_bits = np.asarray(cand.as_array(), dtype=np.uint8).copy()
+            sobs, srew, sdone, sflag = env.simulate(cand, do_sum=False)
+            scode, stoo, sbr, slc, snc = classify(sflag)
+            sim['step'].append(step), sim['action'].append(cand_bits), sim['done'].append(bool(sdone)), sim['flag'].append(scode)
+            sim['action_after'].append(np.asarray(game.last_action.as_array(), dtype=np.uint8).copy())
+            sim['ill_too_many'].append(stoo), sim['ill_counts'].append([int(sbr.sum()), int(slc.sum()), int(snc.sum())])
+            r = np.full(5, np.nan)
+            r[:len(srew)] = srew
+            sim['reward'].append(r)
+            sim['obs'].append(np.full(nobs, np.nan) if sobs is None else np.asarray(sobs, dtype=np.float64))
+        action = draw_action(rng, env, step, spec.get('mix', 'gentle'), recent)
+        submitted = np.asarray(action.as_array(), dtype=np.uint8).copy()     # BEFORE step: the repair edits the object
+        obs, reward, done, flag = env.step(action, do_sum=False)
+        code, too_many, broken, line_cd, node_cd = classify(flag)
         rec['action'].append(submitted)
         # the Action object RunEnv built from the submission (environment.py:860), repaired in place by Game.step
         # (game.py:809-846): what the reward signal is given
@@ -376,6 +401,17 @@ def run_scenario(name):
             out['step_' + k] = np.asarray([st[k] for st in state_step])
             out['after_' + k] = np.asarray([state_after[t][k] for t in ended]).reshape((len(ended),) + np.shape(initial[k]))
     out['init_obs'] = np.asarray(initial_obs, dtype=np.float64)
+    if spec.get('simulate'):
+        out['sim_step'] = np.asarray(sim['step'], dtype=np.int32)
+        out['sim_action'] = np.packbits(np.asarray(sim['action'], dtype=np.uint8).reshape(len(sim['step']), -1), axis=1)
+        out['sim_done'], out['sim_flag'] = np.asarray(sim['done']), np.asarray(sim['flag'])
+        out['sim_action_after'] = np.packbits(np.asarray(sim['action_after'], dtype=np.uint8).reshape(len(sim['step']), -1), axis=1)
+        out['sim_ill_too_many'] = np.asarray(sim['ill_too_many'])
+        out['sim_ill_counts'] = np.asarray(sim['ill_counts'], dtype=np.int32).reshape(len(sim['step']), 3)
+        out['sim_reward'] = np.asarray(sim['reward']).reshape(len(sim['step']), 5)
+        keep = [k for k in range(len(sim['step'])) if k % 3 == 0 or nobs < 2000]      # simulated observations: all (small cases) / every third
+        out['sim_obs_index'] = np.asarray(keep, dtype=np.int32)
+        out['sim_obs'] = np.asarray([sim['obs'][k] for k in keep]).reshape(len(keep), nobs)
     out['action_length'] = np.int32(env.action_space.action_length)
     meta = dict(scenario=name, reference_env=spec['env'], fixture_env=spec['fixture_env'], game_over_mode=spec['mode'],
                 solver=spec.get('solver', 'fdxb'), mix=spec.get('mix', 'gentle'), conf=spec.get('conf', {}), limits=spec.get('limits'),
