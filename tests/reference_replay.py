@@ -49,9 +49,28 @@ class Run(object):
             self.sims = {int(t): k for k, t in enumerate(self.z['sim_step'])}
             self.sim_obs = {int(k): j for j, k in enumerate(self.z['sim_obs_index'])}
 
+    @property
+    def looping(self):
+        return self.meta.get('looping', 'natural')
+
+    @property
+    def start_id(self):
+        return int(self.meta.get('start_id', 0))
+
+    @property
+    def no_cutoff(self):
+        return bool(self.meta.get('without_overflow_cutoff', False))
+
+    def play_order(self):
+        """Chronics in the order an engine holds them: slot 0 = the first one played (pypownet_amd/game.py does the same)."""
+        n, first = len(self.chronics), self.start_id
+        order = [first] if self.looping == 'fixed' else [(first + k) % n for k in range(n)]
+        return [self.chronics[k] for k in order], order
+
     def oracle_game(self):
         return OracleGame(self.case, self.conf, self.chronics, game_over_mode=self.meta['game_over_mode'],
-                          thermal_limits=self.limits)
+                          thermal_limits=self.limits, start_id=self.start_id, looping_mode=self.looping,
+                          without_overflow_cutoff=self.no_cutoff)
 
     def int_state(self, prefix, k):
         z = self.z
@@ -161,6 +180,8 @@ def replay_oracle(name):
         if t in run.sims:
             counts['sims'] = counts.get('sims', 0) + _check_oracle_simulate(run, g, run.sims[t], where)
         before = (g.reconnectable.copy(), g.line_cooldown.copy(), g.node_cooldown.copy())
+        if 'valid' in z:
+            assert g.is_action_valid(run.actions[t].astype(np.int64)) == bool(z['valid'][t]), '%s: is_action_valid %s' % (name, where)
         obs, flag, bits, done = g.step(run.actions[t].astype(np.int64).copy())
         assert bool(done) == bool(z['done'][t]), '%s: done differs %s' % (name, where)
         want_flag = int(z['flag'][t])
@@ -209,19 +230,22 @@ def replay_oracle(name):
 
 
 # ---- (b) an engine library ---------------------------------------------------------------------------------------------------
-def _engine_ints(eng, chronics, b=0):
+def _engine_ints(eng, chronics, b=0, order=None):
     slot, row = int(eng.read('CHRONIC_SLOT')[b]), int(eng.read('CHRONIC_ROW')[b])
+    if order is not None:        # engine slot -> index in the sorted chronic list the fixture counts in
+        chronics = [chronics[k] for k in order]
     return dict(line_status=eng.read('LINES_STATUS')[b], prods_nodes=eng.read('PRODS_NODES')[b],
                 loads_nodes=eng.read('LOADS_NODES')[b], or_nodes=eng.read('LINES_OR_NODES')[b],
                 ex_nodes=eng.read('LINES_EX_NODES')[b], reconnectable=eng.read('RECONNECTABLE')[b],
                 line_cooldown=eng.read('LINE_COOLDOWN')[b], node_cooldown=eng.read('NODE_COOLDOWN')[b],
-                soft_count=eng.read('SOFT_COUNT')[b], chronic=slot,
+                soft_count=eng.read('SOFT_COUNT')[b], chronic=slot if order is None else order[slot],
                 timestep_id=chronics[slot].get_timestep_ids()[row] if row >= 0 else -1, bus_type=eng.read('BUS_TYPE')[b])
 
 
 def _cmp_engine_ints(run, eng, want, where, skip=()):
+    order = run.play_order()[1]
     for b in range(eng.batch):
-        got = _engine_ints(eng, run.chronics, b)
+        got = _engine_ints(eng, run.chronics, b, order)
         for k, w in want.items():
             if k in skip:
                 continue
@@ -276,8 +300,10 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
     from harness import engine_with_library
     run = Run(name)
     z = run.z
-    eng = engine_with_library(lib_path, run.case, run.conf, batch, chronics=run.chronics, thermal_limits=run.limits,
-                              game_over_mode=run.meta['game_over_mode'])
+    limits = run.limits if run.limits is not None else run.chronics[run.start_id].get_imaps()      # (q1: the FIRST chronic played)
+    eng = engine_with_library(lib_path, run.case, run.conf, batch, chronics=run.play_order()[0], thermal_limits=limits,
+                              game_over_mode=run.meta['game_over_mode'], looping_mode=run.looping,
+                              without_overflow_cutoff=run.no_cutoff)
     eng.reset()
     if bool(eng.read('DONE')[0]):
         eng.process_game_over()
@@ -313,6 +339,9 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
                 counts['sims'] = counts.get('sims', 0) + 1
             for f, v in before.items():          # Game.simulate leaves no trace (K10)
                 assert np.array_equal(eng.read(f), v, equal_nan=True), '%s: simulate left a trace in %s %s' % (name, f, where)
+        if 'valid' in z:
+            assert list(eng.is_action_valid(np.repeat(run.actions[t][None, :], batch, axis=0))) == [bool(z['valid'][t])] * batch, \
+                '%s: is_action_valid %s' % (name, where)
         eng.step(np.repeat(run.actions[t][None, :], batch, axis=0), auto_reset=False)
         done, flag, bits = eng.read('DONE'), eng.read('FLAG'), eng.read('ILLEGAL')
         want_flag = int(z['flag'][t])
@@ -387,12 +416,15 @@ def replay_runenv(lib_path, name, max_steps=None):
     counts = dict(steps=0, done=0, illegal=0, obs=0, islands=0)
     with harness.library(lib_path):
         env = penv.RunEnv(os.path.join(ROOT, 'tests', 'golden', 'envs', run.meta['fixture_env']), 'level0',
-                          game_over_mode=run.meta['game_over_mode'], config_overrides=overrides)
+                          chronic_looping_mode=run.looping, start_id=run.start_id, game_over_mode=run.meta['game_over_mode'],
+                          without_overflow_cutoff=run.no_cutoff, config_overrides=overrides)
         env.reward_signal = DefaultGridRewardSignal(run.case.nS)
         np.testing.assert_allclose(env.get_observation(), z['init_obs'], rtol=0, atol=TOL_ENGINE_FLOW)
         for t in range(run.steps if max_steps is None else min(run.steps, max_steps)):
             where = '%s at step %d' % (name, t)
             action = env.action_space.array_to_action(run.actions[t].astype(int))
+            if 'valid' in z:
+                assert env.is_action_valid(action) == bool(z['valid'][t]), where
             obs, reward, done, flag = env.step(action, do_sum=False)
             want = int(z['flag'][t])
             if isinstance(flag, penv.DivergingLoadflowException) and want != 1 and 'not connexe' in flag.text \

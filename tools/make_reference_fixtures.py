@@ -75,6 +75,14 @@ SCENARIOS = {
                                          seed=36, limits='limits_a', solver='newton', mix='wild'),
     'default118_dc_soft':    dict(env='parameters/default118', fixture_env='default118', mode='soft', steps=200, seed=37,
                                   limits='limits_a', conf={'loadflow_mode': 'DC'}),
+    # the other constructor arguments of RunEnv (environment.py:789-791): a fixed chronic from a start id, overflow cut-off disabled
+    'default14_fixed_start3_hard': dict(env='parameters/default14', fixture_env='default14', mode='hard', steps=200, seed=51,
+                                        looping='fixed', start_id=3),
+    'default14_natural_start7_hard': dict(env='parameters/default14', fixture_env='default14', mode='hard', steps=200, seed=54,
+                                          start_id=7),
+    'hard_overflow14_nocutoff_soft': dict(env='tests/parameters/default14_for_tests_hard_overflow',
+                                          fixture_env='default14_for_tests_hard_overflow', mode='soft', steps=120, seed=53,
+                                          without_overflow_cutoff=True),
     # Game.simulate (game.py:887-943) interleaved with the steps: a candidate action is simulated before about every third step
     # (planned injections of the CURRENT entry, no hazards, nothing may leak into the game) and its result recorded as well
     'default14_simulate_soft':  dict(env='parameters/default14', fixture_env='default14', mode='soft', steps=250, seed=41,
@@ -302,12 +310,13 @@ def run_scenario(name):
     import pypownet.environment as renv
     import pypownet.game as rgame
 
-    env = renv.RunEnv(parameters_folder=folder, game_level='level0', chronic_looping_mode='natural', start_id=0,
-                      game_over_mode=spec['mode'])
+    env = renv.RunEnv(parameters_folder=folder, game_level='level0', chronic_looping_mode=spec.get('looping', 'natural'),
+                      start_id=spec.get('start_id', 0), game_over_mode=spec['mode'],
+                      without_overflow_cutoff=spec.get('without_overflow_cutoff', False))
     game = env.game
     rng = np.random.RandomState(spec['seed'])
     nobs = len(env.get_observation())
-    rec = dict(action=[], action_after=[], done=[], flag=[], ill_too_many=[], ill_broken=[], ill_line_cd=[], ill_node_cd=[], reward=[],
+    rec = dict(action=[], action_after=[], valid=[], done=[], flag=[], ill_too_many=[], ill_broken=[], ill_line_cd=[], ill_node_cd=[], reward=[],
                obs=[], obs_after=[], n_loads_cut=[], n_prods_cut=[], n_restarts=[])
     state_step, state_after = [], []
     initial = game_state(game, chron_names)
@@ -351,6 +360,7 @@ def run_scenario(name):
             sim['obs'].append(np.full(nobs, np.nan) if sobs is None else np.asarray(sobs, dtype=np.float64))
         action = draw_action(rng, env, step, spec.get('mix', 'gentle'), recent)
         submitted = np.asarray(action.as_array(), dtype=np.uint8).copy()     # BEFORE step: the repair edits the object
+        rec['valid'].append(bool(env.is_action_valid(action)))               # Game.is_action_valid (game.py:755-760): no side effect
         obs, reward, done, flag = env.step(action, do_sum=False)
         code, too_many, broken, line_cd, node_cd = classify(flag)
         rec['action'].append(submitted)
@@ -414,7 +424,8 @@ def run_scenario(name):
         out['sim_obs'] = np.asarray([sim['obs'][k] for k in keep]).reshape(len(keep), nobs)
     out['action_length'] = np.int32(env.action_space.action_length)
     meta = dict(scenario=name, reference_env=spec['env'], fixture_env=spec['fixture_env'], game_over_mode=spec['mode'],
-                solver=spec.get('solver', 'fdxb'), mix=spec.get('mix', 'gentle'), conf=spec.get('conf', {}), limits=spec.get('limits'),
+                solver=spec.get('solver', 'fdxb'), mix=spec.get('mix', 'gentle'), looping=spec.get('looping', 'natural'),
+                start_id=spec.get('start_id', 0), without_overflow_cutoff=bool(spec.get('without_overflow_cutoff', False)), conf=spec.get('conf', {}), limits=spec.get('limits'),
                 chronics=chron_names, seed=spec['seed'], steps=spec['steps'],
                 flag_codes=dict(none=0, diverged=1, too_many_loads=2, too_many_prods=3, illegal=4),
                 generated_by='tools/make_reference_fixtures.py: the reference\'s RunEnv/Game/Grid imported in place, '
