@@ -268,6 +268,9 @@ struct DevState {
 // (i,j), the row of the P_i equation (dP_i/dVa_j, dP_i/dVm_j); the Q plane holds the row of the Q_i equation only for buses
 // that have one (PQ buses: nv == 2).  A PV bus or the reference bus has no Q row, so its entries take no Q storage: qrel[i] is
 // the byte offset that turns entry index e of a row-i entry into its Q half ((char*)lu + qrel[i] + 16 e), 0xFFFF = no Q row.
+#ifndef PPN_TAIL_BUSES
+#define PPN_TAIL_BUSES 6          // multiple of 2, at most 8 (2 rows per bus in one DPP row of 16 lanes); IEEE-118: 6 (a tail of the last 5 levels) measured against 2 / 4 / 8
+#endif
 struct Smem {
   // across the step
   u8 *st, *on, *en, *pn, *ln, *touched;
@@ -276,6 +279,7 @@ struct Smem {
   // across a solve
   u8 *r2s, *nv, *lf, *lt;             // r2s: bus row -> schedule index (every busbar of the schedule; the live ones are those with touched[row])
   u16 *qrel;
+  double* tinv;                       // fast-decoupled kernels: inverses of the dense tails of B' and B'' (2 x T x T, row-major)
   double *vc, *rhs, *zero;            // vc: V = vc[2i] + j vc[2i+1]; zero: {0, 0, 0, 1} = the halves a missing Q row reads as
   // region R
   double* lu;
@@ -330,6 +334,8 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   o = (o + 15) & ~(size_t)15;
   PPN_TAKE(qrel, u16, NB * 2)
   PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
+  S.tinv = nullptr;
+  if (!NT) { PPN_TAKE(tinv, double, 2 * PPN_TAIL_BUSES * PPN_TAIL_BUSES * 8) }
   const size_t r0 = o;
   S.lu = (double*)(base + r0);
   S.amps = (double*)(base + r0);

@@ -31,6 +31,7 @@ def main():
     envname = os.environ.get('PPN_PROF_ENV', bench.ENV_NAME)      # e.g. default14: the W = 1 kernels
     if envname == bench.ENV_NAME:
         case, conf, chronics = bench.load_workload()
+        conf['solver'] = os.environ.get('PPN_PROF_SOLVER', 'newton')
         limits = bench.bench_limits(case)
     else:
         case, conf, chronics = bench.load_env_fixture(envname, os.environ.get('PPN_PROF_SOLVER', 'newton'))
@@ -68,6 +69,12 @@ def main():
         unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
         per = tot[k] / {'iteration': nit, 'env-step': float(B * steps), 'solve': nsolve}[unit]
         print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
+    if conf['solver'] == 'fdxb':
+        for k, name in enumerate(("B', B'' assembly", "factorisation of B', B'' (+ tail inverses, scaled L)", 'V = |V| e^{ja} (+ clears)',
+                                  'mismatch over the Ybus entries', 'norm, right-hand side', 'forward substitution + tail', 'backward substitution + update')):
+            per = tot[16 + k] / (nsolve if k < 2 else nit)
+            print('fdxb: %-52s total %.3e cyc  %8.0f cyc per %s' % (name, tot[16 + k], per, 'solve' if k < 2 else 'half-iteration'))
+        return
     for k, name in ((16, 'LU level bounds + record prefetch'), (17, 'LU phase 0 (invert, y\')'), (18, 'LU phase 1 (U\', forward)'), (19, 'LU phase 2 (Schur)')):
         print('%-28s total %.3e cyc  %8.0f cyc per iteration' % (name, tot[k], tot[k] / nit))
     for k, name in ((20, 'evaluation pass 0 (V, clears)'), (21, 'evaluation pass 1 (Ybus entries)'), (22, 'evaluation pass 2 (buses, norm)')):
