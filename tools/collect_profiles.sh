@@ -21,9 +21,12 @@ PPN_PROF_ENV=default14 python tools/profile_phases.py 1024 20 > $OUT/phase_profi
 PPN_PROF_ENV=default14 python tools/profile_phases.py 16384 10 > $OUT/phase_profile_default14_b16384.txt 2>&1
 python tools/profile_phases.py 1024 8 split > $OUT/phase_profile_split_b1024.txt 2>&1
 python tools/profile_phases.py 32768 4 > $OUT/phase_profile_b32768.txt 2>&1
+PPN_PROF_SOLVER=fdxb python tools/profile_phases.py 4096 10 > $OUT/phase_profile_fdxb_b4096.txt 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 PPN_LAUNCH_ORDER=0 python bench.py --no-cpu-baseline --no-other-configs > $OUT/bench_no_launch_order.json 2>/dev/null
 python bench.py --batch 32768 --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/bench_b32768.json 2>/dev/null
+PPN_BENCH_CHRONICS=2 python bench.py --no-cpu-baseline --no-other-configs > $OUT/bench_2chronics.json 2>/dev/null
+PPN_BENCH_CHRONICS=2 python bench.py --batch 32768 --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/bench_2chronics_b32768.json 2>/dev/null
 tail -1 $OUT/bench.json | cut -c1-400
 ls $OUT $OUT/stats | head -30
 # afterwards, in the development container: python tools/summarize_pmc.py $TAG  (-> profiles/)

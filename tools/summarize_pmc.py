@@ -58,7 +58,9 @@ def main():
                  ('stats_all/bench_all_kernel_stats.csv', '_bench_all_configs_rocprofv3_kernel_stats.csv'),
                  ('phase_profile_default14_b1024.txt', '_phase_profile_default14_b1024.txt'),
                  ('phase_profile_default14_b16384.txt', '_phase_profile_default14_b16384.txt'),
-                 ('phase_profile_split_b1024.txt', '_phase_profile_split_b1024.txt')):
+                 ('phase_profile_split_b1024.txt', '_phase_profile_split_b1024.txt'),
+                 ('phase_profile_fdxb_b4096.txt', '_phase_profile_fdxb_b4096.txt'),
+                 ('bench_2chronics.json', '_bench_2chronics.json'), ('bench_2chronics_b32768.json', '_bench_2chronics_b32768.json')):
         if os.path.exists(os.path.join(src, a)):
             shutil.copyfile(os.path.join(src, a), os.path.join(dst, tag + b))
     # the bench lines were printed before this summary existed: give them the traffic measured on the same build
