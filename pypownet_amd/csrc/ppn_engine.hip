@@ -25,7 +25,7 @@
 // device memory abstraction (HIP, or plain host memory in the test-only emulation build)
 #ifdef PPN_EMU
 typedef int hipStream_t;
-static int dev_malloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? 0 : -1; }
+static int dev_malloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xA5, n ? n : 1); return *p ? 0 : -1; }   // (device memory is not zeroed either)
 static void dev_free(void* p) { free(p); }
 static int dev_h2d(void* d, const void* h, size_t n, hipStream_t) { memcpy(d, h, n); return 0; }
 static int dev_d2h(void* h, const void* d, size_t n, hipStream_t) { memcpy(h, d, n); return 0; }
@@ -151,7 +151,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   Smem S;
   ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS);
   for (int env = 0; env < nblocks; ++env) {
-    memset(base, 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
+    memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
     if (KIND == K_STEP || KIND == K_ROLLOUT) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);

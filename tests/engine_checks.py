@@ -253,7 +253,7 @@ def check_auto_reset_and_cascade_118(lib_path, steps=25, batch=6, solver='newton
         assert np.array_equal(orc.read('CASCADE_DEPTH'), a.read('CASCADE_DEPTH'))
         b.process_game_over()
         for f in ('LINES_STATUS', 'RECONNECTABLE', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES'):
-            assert np.array_equal(a.read(f), b.read(f)), f
+            assert np.array_equal(a.read(f), b.read(f)), (f, t, a.read(f), b.read(f), orc.read(f), a.read('N_ITERS'), b.read('N_ITERS'), orc.read('N_ITERS'))
             assert np.array_equal(a.read(f), orc.read(f)), f
         for f in ('VM', 'VA', 'PF', 'AMPS'):
             assert np.array_equal(a.read(f), b.read(f)), f

@@ -24,7 +24,7 @@ def main():
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     if not os.path.exists(lib) or os.environ.get('PPN_REBUILD'):
       subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-                           '-DPPN_PROF', os.path.join(ROOT, 'pypownet_amd', 'csrc', 'ppn_engine.hip'), '-o', lib])
+                           '-DPPN_PROF'] + os.environ.get('PPN_PROF_FLAGS', '').split() + [os.path.join(ROOT, 'pypownet_amd', 'csrc', 'ppn_engine.hip'), '-o', lib])
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     split = len(sys.argv) > 3 and sys.argv[3] == 'split'     # random node-splitting actions, every busbar may be active
