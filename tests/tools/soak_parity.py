@@ -20,6 +20,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     case, conf, chronics = bench.load_workload()
+    conf['solver'] = os.environ.get('PPN_SOAK_SOLVER', conf['solver'])      # (fdxb: the reference's own solver)
     lim = bench.bench_limits(case)
     eng = Engine(case, conf, B, chronics=chronics, thermal_limits=lim, max_active_buses=case.nS)
     orc = oracle_engine(case, conf, B, chronics=chronics, thermal_limits=lim)
