@@ -157,3 +157,13 @@ def test_emu_restart_goes_on_after_the_attempt_cap(emu_lib):
 def test_emu_rollout_equals_steps(emu_lib):
     assert ec.check_rollout_equals_steps(emu_lib, 'default14_for_tests_alpha', batch=12, n_steps=12, bench_limits=False, random_acts=True) > 0
     assert ec.check_rollout_equals_steps(emu_lib, 'default118', batch=6, n_steps=5, modes=(2,)) >= 0
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb', 'dc'])
+def test_emu_with_nan_poisoned_lds(emu_lib, solver, monkeypatch):
+    """LDS is not zeroed between workgroups on the GPU.  The emulation normally fills it with 0xA5 bytes (tiny negative doubles);
+    filled with 0xFF every double a kernel reads before writing it is a NaN and every u8 / u16 index is out of range: a step on
+    the cascade workload (restarts, cascades, all solver flavours) must come out the same."""
+    monkeypatch.setenv('PPN_EMU_LDS_FILL', '255')
+    ec.check_auto_reset_and_cascade_118(emu_lib, steps=6, batch=4, solver=solver) if solver != 'dc' else \
+        ec.check_do_nothing(emu_lib, 'default14_for_tests_beta', 'dc', steps=6, batch=2)
