@@ -63,6 +63,10 @@ SCENARIOS = {
     'default30_hard':        dict(env='parameters/default30', fixture_env='default30', mode='hard', steps=250, seed=22,
                                   mix='wild'),
     'default118_soft':       dict(env='parameters/default118', fixture_env='default118', mode='soft', steps=200, seed=31),
+    'default118_wild_soft':  dict(env='parameters/default118', fixture_env='default118', mode='soft', steps=120, seed=38,
+                                  mix='wild'),
+    'default30_wild_hard':   dict(env='parameters/default30', fixture_env='default30', mode='hard', steps=150, seed=23,
+                                  mix='wild'),
     'default118_hard':       dict(env='parameters/default118', fixture_env='default118', mode='hard', steps=200, seed=32,
                                   mix='wild'),
     'default118_tight_soft': dict(env='parameters/default118', fixture_env='default118', mode='soft', steps=200, seed=33,
