@@ -5,7 +5,7 @@ ROOT=os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/tools'); sys.path.insert(0, ROOT+'/tests')
 import bench
 from harness import engine_with_library
-lib=os.path.join(ROOT,'build','libppn_prof.so')
+lib=os.environ.get('PPN_PROF_LIB', os.path.join(ROOT,'build','libppn_prof.so'))
 case, conf, chronics = bench.load_workload()
 B=4096
 eng=engine_with_library(lib, case, conf, B, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
@@ -22,9 +22,9 @@ for rep in range(4):
     kt=eng.kernel_time()
     out=np.zeros((B,32),dtype=np.int64)
     eng._check(eng._lib.ppn_read(eng._h,100,out.ctypes.data,out.nbytes,1,0),'r')
-    flag=eng.read('FLAG')
+    flag=eng.read('FLAG'); depth=eng.read('CASCADE_DEPTH')
     w=out[:,15]*1e-8*1e6  # us
     print('auto_reset %d: kernel %.0f us | env body wall us: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | sum/kernel = %.0f resident' % (AR, kt[0]/kt[1]*1e3, w.mean(), np.percentile(w,50), np.percentile(w,90), np.percentile(w,99), w.max(), w.sum()/(kt[0]/kt[1]*1e3)))
     top=np.argsort(-w)[:6]
     for e in top:
-        print('   env %4d body %.0f us: prologue %.0f us, cascade %.0f us, restart (fused or owed) %.0f us (flag %d)' % (e, w[e], out[e,9]/2370., out[e,10]/2370., out[e,11]/2370., flag[e]))
+        print('   env %4d body %.0f us: prologue %.0f us, cascade %.0f us, restart (fused or owed) %.0f us (flag %d, cascade depth %d, short re-solves so far %d)' % (e, w[e], out[e,9]/2370., out[e,10]/2370., out[e,11]/2370., flag[e], depth[e], out[e,30]))

@@ -14,13 +14,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 NAMES = ['connectivity (adjacency + BFS)', 'schedule check (+rebuild)', 'live buses/injections/types', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
          'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)', 'restart of ended episodes (incl its solves)',
-         'cut flags + topology write-back']
+         'cut flags + topology write-back', 'results into LDS / registers, NaN test (per solve)']
 
 
 def main():
     import bench
     from harness import engine_with_library      # (tests/harness.py: the profiling build is not the product library)
-    lib = os.path.join(ROOT, 'build', 'libppn_prof.so')
+    lib = os.environ.get('PPN_PROF_LIB', os.path.join(ROOT, 'build', 'libppn_prof.so'))
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     if not os.path.exists(lib) or os.environ.get('PPN_REBUILD'):
       subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
@@ -66,9 +66,12 @@ def main():
     nsolve, nit = float(s1 - s0), float(i1 - i0)
     print('B=%d steps=%d solves=%d iterations=%d' % (B, steps, nsolve, nit))
     for k, name in enumerate(NAMES):
+        if k == 13 and tot[k] == 0:
+            continue       # (builds before round 4 have no such phase)
         unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
         per = tot[k] / {'iteration': nit, 'env-step': float(B * steps), 'solve': nsolve}[unit]
         print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
+    print('cascade re-solves that took the short way in: %d of %d solves' % (tot[30], nsolve))
     if conf['solver'] == 'fdxb':
         for k, name in enumerate(("B', B'' assembly", "factorisation of B', B'' (+ tail inverses, scaled L)", 'V = |V| e^{ja} (+ clears)',
                                   'mismatch over the Ybus entries', 'norm, right-hand side', 'forward substitution + tail', 'backward substitution + update')):
