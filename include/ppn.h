@@ -182,6 +182,8 @@ typedef enum ppn_field {
   PPN_F_DEAD,              /* u8 [1]    0 playing; 1 over: the next step skips it until it is restarted; 2 over, its restart is
                                         owed by the next ppn_step(auto_reset = 2) (never seen after ppn_sync); 3 over, and
                                         PPN_RESTART_ATTEMPTS restarts in a row diverged as well (see ppn_process_game_over) */
+  PPN_F_EPOCH,             /* i32 [1]   Game.epoch (game.py:333, 767): 1 after ppn_reset, + 1 for EVERY restart attempt of
+                                        process_game_over -- the reference increments it on each recursive call too            */
   PPN_F_COUNT
 } ppn_field;
 
@@ -246,7 +248,12 @@ int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, i
  * ppn_step(actions[s], ..., auto_reset): the report fields (PPN_F_DONE, FLAG, REWARD ...) are those of the LAST step,
  * PPN_F_N_STEPS / PPN_F_RETURN accumulate over all of them.  What differs is the schedule: no environment waits for another
  * one between its steps, so a launch no longer lasts n_steps times its longest cascade (measurement).
- * auto_reset as in ppn_step (0: an environment that ends sits out the remaining steps). */
+ * auto_reset as in ppn_step (0: an environment that ends sits out the remaining steps).
+ * ONE exception to "same outcome": an environment that is ALREADY over when the rollout starts (right after ppn_reset on a
+ * grid that diverges, or after steps with auto_reset = 0) is restarted BEFORE its first step and plays all n_steps steps;
+ * under n_steps calls of ppn_step(auto_reset != 0) it sits out the first call and is restarted in that call's post-pass
+ * (n_steps - 1 steps).  Call ppn_process_game_over first and the two agree again (tests: check_rollout_equals_steps does,
+ * check_rollout_dead_at_start pins the exception). */
 int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t n_steps,
                 int32_t per_step_actions, int32_t auto_reset);
 /* Topology-action search (the reference's search agents call RunEnv.simulate once per candidate,
@@ -263,7 +270,9 @@ int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, int32_t actio
  * bound, i.e. until Python's recursion limit ends the process).  One pass of the engine stops after PPN_RESTART_ATTEMPTS
  * and leaves such an environment over with PPN_F_DEAD = 3: call again to go on (pypownet_amd.game.Game does, up to the
  * reference's ~1000 frames), or keep stepping with auto_reset -- every ppn_step(auto_reset != 0) launch takes up the restart of
- * its DEAD = 3 environments again before their step.  Such an environment executes no step meanwhile: PPN_F_N_STEPS. */
+ * its DEAD = 3 environments again before their step.  Such an environment executes no step meanwhile (PPN_F_N_STEPS) and its
+ * report fields (PPN_F_DONE = 1, FLAG, CASCADE_DEPTH, REWARD) stay those of the step that ended its episode: a consumer that
+ * counts episode ends per launch masks them with "PPN_F_N_STEPS moved" (bench.py does) or with PPN_F_DEAD != 3. */
 #define PPN_RESTART_ATTEMPTS 64
 int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask);
 /* Game.is_action_valid (game.py:755-760): valid[b] = 1/0. */
@@ -296,7 +305,10 @@ int ppn_runpf_batch(ppn_engine* e);
  * Host pointers only; the call synchronises. */
 typedef struct ppn_mpc_batch {
   int32_t n;
-  int32_t bus_cols, gen_cols, branch_cols;     /* columns of the input arrays: >= 13 (10 are read), >= 8, >= 11 */
+  int32_t bus_cols, gen_cols, branch_cols;     /* columns of the input arrays: >= 10 (MATPOWER writes 13), >= 8, >= 11 */
+  int32_t bus_rows, gen_rows, branch_rows;     /* rows of ONE case in the arrays below: must be 2 nS, nP, nl of the engine's case --
+                                                  an mpc with isolated buses dropped or without the '666'-twin rows is refused
+                                                  (PPN_E_INVALID), not read past its end */
   const double* bus;                           /* [n x 2nS x bus_cols] */
   const double* gen;                           /* [n x nP x gen_cols] */
   const double* branch;                        /* [n x nl x branch_cols] */

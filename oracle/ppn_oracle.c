@@ -884,6 +884,7 @@ static int field_ptr(const OCase* c, OEnv* e, ppn_field f, void** p, size_t* byt
     case PPN_F_LINE_EVENTS: A(e->lev, c->nl, uint8_t) case PPN_F_SOLVE_OUTCOME: S(e->src)
     case PPN_F_N_SOLVES: S(e->nsolve) case PPN_F_N_ITERS: S(e->niter) case PPN_F_CHRONIC_SLOT: S(e->slot)
     case PPN_F_CHRONIC_ROW: S(e->row) case PPN_F_N_LOADS_CUT: S(e->nlc) case PPN_F_N_PRODS_CUT: S(e->npc)
+    case PPN_F_EPOCH: S(e->epoch)
     default: return -1;
   }
 #undef A

@@ -45,6 +45,7 @@ class PpnMpcBatch(C.Structure):
     """ppn_mpc_batch (include/ppn.h): MATPOWER arrays of n cases in, result arrays out."""
     _dp = C.POINTER(C.c_double)
     _fields_ = [('n', C.c_int32), ('bus_cols', C.c_int32), ('gen_cols', C.c_int32), ('branch_cols', C.c_int32),
+                ('bus_rows', C.c_int32), ('gen_rows', C.c_int32), ('branch_rows', C.c_int32),
                 ('bus', _dp), ('gen', _dp), ('branch', _dp), ('bus_out', _dp), ('gen_out', _dp), ('branch_out', _dp),
                 ('success', C.POINTER(C.c_uint8)), ('outcome', C.POINTER(C.c_int32))]
 
@@ -61,7 +62,7 @@ FIELDS = ['VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMP
           'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN',
           'SOFT_COUNT', 'DONE', 'FLAG', 'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT',
           'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE', 'REWARD', 'ILLEGAL_COUNTS',
-          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'RETURN', 'DEAD']
+          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'RETURN', 'DEAD', 'EPOCH']
 FIELD_ID = {k: i for i, k in enumerate(FIELDS)}
 _F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD', 'RETURN'}
 _U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE',

@@ -272,7 +272,7 @@ class BatchedRunEnv(object):
         (``Engine.step_device``) and writes done / flag / reward into device tensors that are gathered as they are; the root
         gets torch CUDA tensors back.  With "gloo" (CPU tests) the same exchange runs through host arrays."""
         import torch.distributed as dist
-        if self.world_size > 1 and dist.get_backend() == 'nccl':
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':      # (also a world of ONE rank: the RCCL path on the hardware at hand)
             return self._controller_step_device(global_actions, root, auto_reset)
         acts = self.scatter_from_root(global_actions, root=root)
         self.engine.step(acts, auto_reset=auto_reset)

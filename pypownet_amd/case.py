@@ -56,6 +56,22 @@ def save_case_json(ppc, path):
                    'branch': np.asarray(ppc['branch']).tolist()}, f)
 
 
+def save_case_py(ppc, path):
+    """The PYPOWER case format the reference's tooling writes (``savecase(output_file, mpc)``, parameters/make_reference_grid.py:63)
+    and its environments ship (``parameters/<env>/<level>/reference_grid.py``, read back by ``loadcase``, pypownet/grid.py:65): a
+    module with ONE function named after the file, returning the case dict; numbers at full precision (repr round-trips)."""
+    fname = os.path.splitext(os.path.basename(path))[0]
+
+    def rows(a):
+        return ',\n'.join('        [' + ', '.join(repr(float(v)) for v in r) + ']' for r in np.asarray(a, dtype=np.float64))
+    with open(path, 'w') as f:
+        f.write('from numpy import array\n\n\ndef %s():\n    ppc = {"version": %r}\n\n' % (fname, str(ppc.get('version', '2'))))
+        f.write('    ppc["baseMVA"] = %r\n\n' % float(ppc['baseMVA']))
+        for k in ('bus', 'gen', 'branch'):
+            f.write('    ppc[%r] = array([\n%s\n    ])\n\n' % (k, rows(ppc[k])))
+        f.write('    return ppc\n')
+
+
 def twin_id(sub_id):
     """External id of the artificial busbar of substation ``sub_id`` ('666' string prefix)."""
     return float(ARTIFICIAL_NODE_STARTING_STRING + str(int(sub_id)))

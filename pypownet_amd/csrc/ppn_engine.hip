@@ -379,6 +379,7 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
     case PPN_F_N_STEPS: FI(nstep, int, 1, false)
     case PPN_F_RETURN: FI(ret, double, 1, false)
     case PPN_F_DEAD: FI(dead, u8, 1, false)
+    case PPN_F_EPOCH: FI(epoch, int, 1, false)
     default: return false;
   }
 #undef FI

@@ -255,9 +255,11 @@ class Engine(object):
         if bus.ndim == 2:
             bus, gen, branch = bus[None], gen[None], branch[None]
         n = bus.shape[0]
-        assert gen.shape[0] == n and branch.shape[0] == n
+        if bus.ndim != 3 or gen.ndim != 3 or branch.ndim != 3 or gen.shape[0] != n or branch.shape[0] != n:
+            raise ValueError('runpf_arrays: bus / gen / branch must be [n x rows x columns] arrays of the same n')
         io = _lib.PpnMpcBatch()
         io.n, io.bus_cols, io.gen_cols, io.branch_cols = n, bus.shape[2], gen.shape[2], branch.shape[2]
+        io.bus_rows, io.gen_rows, io.branch_rows = bus.shape[1], gen.shape[1], branch.shape[1]      # (checked against the case by the library)
         bus_o, gen_o = np.empty_like(bus), np.empty_like(gen)
         br_o = np.empty((n, branch.shape[1], 17), dtype=np.float64)
         ok, outcome = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.int32)

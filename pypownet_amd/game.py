@@ -370,16 +370,17 @@ class Game(object):
         return self.step(action, _is_simulation=True)
 
     def process_game_over(self):
-        self.epoch += 1
         self.engine.force_game_over()
         # the reference recurses until a restart converges (game.py:776-780); one engine pass gives up after 64 attempts
         # (include/ppn.h, PPN_RESTART_ATTEMPTS): go on, up to about what Python's recursion limit allows the reference
         for _ in range(15):
             if int(self.engine.read('DEAD')[0]) != 3:
-                return
+                break
             self.engine.process_game_over()
+        # the reference increments epoch on every (recursive) attempt, game.py:767: so does the device counter
+        self.epoch = int(self.engine.read('EPOCH')[0])
         if int(self.engine.read('DEAD')[0]) == 3:
-            raise RecursionError('process_game_over: the restarted grid keeps diverging (960 attempts)')
+            raise RecursionError('process_game_over: the restarted grid keeps diverging (1024 attempts = 16 passes of 64)')
 
     def reset_grid(self):
         raise NotImplementedError('reset_grid is internal to process_game_over on the device engine')

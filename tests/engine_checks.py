@@ -796,6 +796,13 @@ def check_runpf_arrays(lib_path, envname, n, solver='newton', dc=False, seed=77,
     bad[0, 0, 3] *= 1.5
     with pytest_raises_engine_error():
         eng.runpf_arrays(bus, gen, bad)
+    # ... and so is an mpc of another shape (isolated buses dropped, no '666'-twin rows): PPN_E_INVALID, no read past the end
+    with pytest_raises_engine_error():
+        eng.runpf_arrays(bus[:, :case.nS], gen, br)
+    with pytest_raises_engine_error():
+        eng.runpf_arrays(bus, gen[:, :-1], br)
+    with pytest_raises_engine_error():
+        eng.runpf_arrays(bus, gen, br[:, :-1])
     eng.close()
     return seen
 
@@ -804,6 +811,43 @@ def pytest_raises_engine_error():
     import pytest
     from pypownet_amd.engine import EngineError
     return pytest.raises(EngineError)
+
+
+def check_rollout_dead_at_start(lib_path, batch=64, n_steps=5):
+    """include/ppn.h, ppn_rollout's documented exception: an environment that is over when the rollout starts is restarted
+    FIRST and plays all n_steps steps; under ppn_step(auto_reset = 1) it sits out the first call (n_steps - 1 steps).
+    Environments that are alive at the start agree bit for bit."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env('default118', conf={'solver': 'newton'})
+    with open(os.path.join(ENVS, 'default118', 'bench_limits.json')) as f:
+        kw = dict(thermal_limits=np.asarray(json.load(f)['limits_a']), max_active_buses=case.nS)
+    slots, t0 = default_assignment(np.arange(batch), chronics)
+    act = np.zeros((batch, case.action_length), dtype=np.uint8)
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)
+    b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)
+    for e in (a, b):
+        e.reset(chronic_slot=slots, t0=t0)
+        e.process_game_over()
+        for _ in range(8):
+            e.step(act, auto_reset=0)          # episodes that end stay over
+    dead = a.read('DEAD') != 0
+    assert dead.any() and not dead.all() and np.array_equal(dead, b.read('DEAD') != 0)
+    n0 = a.read('N_STEPS').copy()
+    for _ in range(n_steps):
+        a.step(act, auto_reset=1)
+    b.rollout(act, n_steps=n_steps, auto_reset=1)
+    na, nb = a.read('N_STEPS') - n0, b.read('N_STEPS') - n0
+    assert (nb == n_steps).all()
+    assert (na[~dead] == n_steps).all() and (na[dead] == n_steps - 1).all()
+    for f in STATE_FIELDS:
+        x, y = a.read(f), b.read(f)
+        assert np.array_equal(x[~dead], y[~dead], equal_nan=x.dtype.kind == 'f'), f
+    a.close()
+    b.close()
+    return int(dead.sum())
 
 
 def check_restart_goes_on(lib_path, batch=16, steps=8):

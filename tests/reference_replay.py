@@ -35,6 +35,7 @@ class Run(object):
         self.actions_after = np.unpackbits(self.z['action_after'], axis=1)[:, :n]
         self.sampled = {int(t): k for k, t in enumerate(self.z['sampled_steps'])}
         self.ended = {int(t): k for k, t in enumerate(self.z['ended_steps'])}
+        self.reduced = {int(t): k for k, t in enumerate(self.z['reduced_steps'])}      # steps with the reference's reduced layouts recorded
         self.ended_sampled = {int(t): k for k, t in enumerate(self.z['ended_sampled_steps'])}
         conf = dict(self.meta['conf'])
         conf['solver'] = self.meta['solver']
@@ -311,7 +312,7 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
     _cmp_engine_floats(run, eng, run.float_state('init_', 0), z['init_bus_type'], 'after construction')
     if check_obs:
         np.testing.assert_allclose(eng.observations()[0], z['init_obs'], rtol=0, atol=TOL_ENGINE_FLOW)
-    counts = dict(done=0, illegal=0, obs=0, islands=0, steps=0)
+    counts = dict(done=0, illegal=0, obs=0, islands=0, steps=0, island_steps=[], sim_islands=[], stopped_at=None)
     for t in range(run.steps):
         where = 'at step %d' % t
         if t in run.sims:
@@ -321,6 +322,8 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
             sd, sf, sb = eng.read('DONE', simulation=True), eng.read('FLAG', simulation=True), eng.read('ILLEGAL', simulation=True)
             want = int(z['sim_flag'][k])
             skip = int(sf[0]) == 1 and want != 1 and int(eng.read('SOLVE_OUTCOME', simulation=True)[0]) == 2      # (island: see below)
+            if skip:      # (the simulated grid is not recorded, so the island cannot be re-derived here: the skip is COUNTED and the
+                counts['sim_islands'].append(t)      #  callers pin which (run, step) pairs may take it -- tests/test_reference_runs.py)
             if not skip:
                 for b in range(batch):
                     assert bool(sd[b]) == bool(z['sim_done'][k]), '%s: simulated done differs %s' % (name, where)
@@ -347,7 +350,9 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
         want_flag = int(z['flag'][t])
         if int(flag[0]) == 1 and want_flag != 1 and int(eng.read('SOLVE_OUTCOME')[0]) == 2 and island_without_reference(run, t):
             counts['islands'] += 1
+            counts['island_steps'].append(t)
             if not z['done'][t]:
+                counts['stopped_at'] = t
                 break
             eng.process_game_over()
             _cmp_engine_ints(run, eng, run.int_state('after_', run.ended[t]), 'after the restart ' + where)
@@ -379,6 +384,15 @@ def replay_engine(lib_path, name, batch=2, check_reward=True, check_obs=True):
                     np.testing.assert_allclose(eng.observations()[0], z['obs'][k], rtol=0, atol=TOL_ENGINE_FLOW,
                                                err_msg='%s obs %s' % (name, where))
                     counts['obs'] += 1
+                    if t in run.reduced:      # what the reference's Observation.as_minimalist() / as_ac_minimalist() returned
+                        for lay, key in (('minimalist', 'obs_minimalist'), ('ac_minimalist', 'obs_ac_minimalist')):
+                            want_o = z[key][run.reduced[t]]
+                            got = eng.observations(layout=lay)[0]
+                            assert got.shape == want_o.shape, (lay, got.shape, want_o.shape)
+                            np.testing.assert_allclose(got, want_o, rtol=0, atol=TOL_ENGINE_FLOW, err_msg='%s %s layout %s' % (name, lay, where))
+                            np.testing.assert_allclose(eng.observations(layout=lay, dtype=np.float32)[0], want_o.astype(np.float32), rtol=1e-6,
+                                                       atol=1e-3, err_msg='%s %s layout (f32) %s' % (name, lay, where))
+                        counts['reduced'] = counts.get('reduced', 0) + 1
         if check_reward and not np.isnan(z['reward'][t]).any():
             # the device reward (PPN_F_REWARD) against what the reference's CustomRewardSignal returned
             np.testing.assert_allclose(eng.read('REWARD')[0], z['reward'][t], rtol=1e-7, atol=1e-6,

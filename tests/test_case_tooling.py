@@ -8,7 +8,7 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tools'))
 from make_reference_grid import make_reference_grid  # noqa: E402
-from pypownet_amd.case import Case, load_case_file  # noqa: E402
+from pypownet_amd.case import Case, load_case_file, save_case_py  # noqa: E402
 
 ENVS = os.path.join(os.path.dirname(__file__), 'golden', 'envs')
 
@@ -26,3 +26,23 @@ def test_twin_generator_reproduces_shipped_reference_grid(env):
     assert np.array_equal(out['gen'][:, :7], ref['gen'][:, :7]) and np.all(out['gen'][:, 7] == 1)
     assert np.array_equal(np.sort(out['branch'][:, :2], axis=0), np.sort(ref['branch'][:, :2], axis=0))
     Case(out)      # accepted by the engine's case model (sorted ids, twins, one production / load per substation)
+
+
+def test_reference_grid_py_round_trip(tmp_path):
+    """The tool writes ``reference_grid.py`` (the format parameters/make_reference_grid.py:63 saves and grid.py:65 loads): read
+    back through the ``loadcase`` contract it is the same case, bit for bit, and the engine's case model takes it."""
+    import subprocess
+    ref = load_case_file(os.path.join(ENVS, 'default30', 'level0', 'reference_grid.json'))
+    n = ref['bus'].shape[0] // 2
+    src = str(tmp_path / 'case30.py')
+    save_case_py(dict(ref, bus=ref['bus'][:n]), src)
+    tool = os.path.join(os.path.dirname(__file__), '..', 'tools', 'make_reference_grid.py')
+    out = subprocess.check_output([sys.executable, tool, src]).decode().strip()
+    assert out.endswith('reference_grid.py') and os.path.dirname(out) == str(tmp_path)
+    back = load_case_file(out)
+    for k in ('bus', 'gen'):
+        assert np.array_equal(back[k], ref[k]), k
+    rows = lambda a: a[np.lexsort(a.T[::-1])]      # (the shipped file keeps its own order among branches of equal origin)
+    assert np.array_equal(rows(back['branch']), rows(ref['branch']))
+    assert back['baseMVA'] == ref['baseMVA']
+    Case(back)

@@ -159,6 +159,10 @@ def test_emu_rollout_equals_steps(emu_lib):
     assert ec.check_rollout_equals_steps(emu_lib, 'default118', batch=6, n_steps=5, modes=(2,)) >= 0
 
 
+def test_emu_rollout_with_environments_over_at_the_start(emu_lib):
+    assert ec.check_rollout_dead_at_start(emu_lib, batch=24, n_steps=4) >= 1
+
+
 @pytest.mark.parametrize('solver', ['newton', 'fdxb', 'dc'])
 def test_emu_with_nan_poisoned_lds(emu_lib, solver, monkeypatch):
     """LDS is not zeroed between workgroups on the GPU.  The emulation normally fills it with 0xA5 bytes (tiny negative doubles);

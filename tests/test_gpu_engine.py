@@ -112,6 +112,10 @@ def test_gpu_restart_goes_on_after_the_attempt_cap():
     assert ec.check_restart_goes_on(HIP, batch=256, steps=12) >= 1
 
 
+def test_gpu_rollout_with_environments_over_at_the_start():
+    assert ec.check_rollout_dead_at_start(HIP, batch=256, n_steps=6) >= 1
+
+
 def test_gpu_rollout_equals_steps():
     """ppn_rollout: n steps per environment in one launch = n ppn_step calls, bit for bit."""
     assert ec.check_rollout_equals_steps(HIP, 'default118', batch=512, n_steps=12) > 100
@@ -212,6 +216,22 @@ def test_gpu_tuned_pattern_capacity():
     the results stay those of the oracle under random node splitting; no environment may hit the capacity flag."""
     st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 20, 48, 'newton', seed=78, lu_capacity=3976)
     assert st['split_buses'] > 0
+
+
+def test_gpu_random_splitting_full_share_of_configs4_tuned():
+    """BASELINE configs[4] in the configuration the bench line quotes -- default118, per-env random
+    node splitting, the per-GPU share of 1024 environments, every busbar may be active (W = 4 kernels), lu_capacity = 3976,
+    q_plane_auto = 1 -- 40 steps of lock-step with the C oracle, zero capacity flags (asserted inside the check)."""
+    st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 40, 1024, 'newton', seed=404, lu_capacity=3976, q_plane_auto=1,
+                                             obs_every=8)
+    assert st['split_buses'] > 0 and st['illegal'] > 0 and st['done'] > 1024
+
+
+def test_gpu_random_splitting_full_share_fdxb_w4():
+    """the four-word FAST-DECOUPLED kernels (256 VGPRs + AGPRs; one code shape there gave wrong flows on the
+    GPU only) in lock-step with the oracle under random node splits at the full per-GPU share."""
+    st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 25, 1024, 'fdxb', seed=405, obs_every=8)
+    assert st['split_buses'] > 0 and st['done'] > 512
 
 
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
@@ -353,6 +373,64 @@ def test_gpu_bench_two_ranks_share_one_gpu(single_controller, tmp_path):
     assert d['config']['env_assignment_crc32'] == want
     # the aggregate: both ranks' environments over the slowest rank's time
     assert abs(d['value'] - 2 * B * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']
+
+
+def test_gpu_rccl_path_on_one_rank(tmp_path):
+    """the RCCL ("nccl" backend) legs of the multi-GPU path on the hardware that exists -- ONE rank.
+    (a) BatchedRunEnv.controller_step with device tensors on a world of one nccl rank: device-resident scatter -> Engine.step_device
+        -> gather of device tensors, compared step by step with the host-array path on a second engine;
+    (b) bench.py --gpus 1 --single-controller with PPN_BENCH_FORCE_DIST=1: the bench's own scatter / step / gather loop over RCCL;
+        its line is kept as profiles/r04_bench_single_controller_1rank.json by tools/collect_profiles.sh."""
+    import json
+    import subprocess
+    import sys
+    port = 29500 + (os.getpid() % 2000)
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='%d', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "from pypownet_amd.batched import BatchedRunEnv\n"
+        "from helpers import ENVS\n"
+        "B = 192\n"
+        "kw = dict(config_overrides={'solver': 'newton'})\n"
+        "a = BatchedRunEnv(os.path.join(ENVS, 'default118'), 'level0', B, rank=0, world_size=1, device=0, **kw)\n"
+        "b = BatchedRunEnv(os.path.join(ENVS, 'default118'), 'level0', B, rank=0, world_size=1, device=0, **kw)\n"
+        "a.reset(); b.reset()\n"
+        "rng = np.random.default_rng(3)\n"
+        "n_done = 0\n"
+        "for t in range(12):\n"
+        "    act = (rng.random((B, a.action_length)) < 0.004).astype(np.uint8)\n"
+        "    done, flag, rew = a.controller_step(torch.from_numpy(act).to('cuda:0'), root=0, auto_reset=True)\n"
+        "    assert done.is_cuda and flag.is_cuda and rew.is_cuda\n"
+        "    b.engine.step(act, auto_reset=True)\n"
+        "    assert np.array_equal(done.cpu().numpy(), b.engine.read('DONE').astype(bool))\n"
+        "    assert np.array_equal(flag.cpu().numpy(), b.engine.read('FLAG'))\n"
+        "    np.testing.assert_allclose(rew.cpu().numpy(), b.engine.read('REWARD').sum(axis=1), rtol=1e-12, atol=1e-9)\n"
+        "    for f in ('VM', 'LINES_STATUS', 'PRODS_NODES', 'N_SOLVES'):\n"
+        "        assert np.array_equal(a.engine.read(f), b.engine.read(f), equal_nan=True), f\n"
+        "    n_done += int(done.sum())\n"
+        "s = a.all_reduce_stats([1.0, float(n_done)])\n"
+        "assert s[0] == 1.0\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('RCCL_ONE_RANK_OK', n_done)\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), port)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'RCCL_ONE_RANK_OK' in out.stdout, out.stderr[-3000:]
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3', '--single-controller',
+           '--no-cpu-baseline', '--no-other-configs']
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PPN_BENCH_BACKEND')}
+    env.update(PPN_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port + 1))
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['config'].get('single_controller') and d['config'].get('dist_backend') == 'nccl', d['config']
+    keep = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, 'r04_bench_single_controller_1rank.json'), 'w') as f:
+            json.dump(d, f, indent=1)
 
 
 def test_gpu_engine_library_first_then_torch():

@@ -35,13 +35,25 @@ def test_numpy_oracle_replays_reference_run(name):
         assert c['sims'] >= 40, c
 
 
+# The ONE class of steps a replay may set aside (reference_replay.island_without_reference: an island without the reference
+# bus, where PYPOWER's outcome is SuperLU's rounding luck) is pinned by (run, step): 2 of 5 140 steps, both in one run.  At step
+# 103 both sides ended the episode and the replay goes on; at step 233 the reference's solve sailed through and its game went
+# on, so the replay stops there.  Every other run replays to its last step with nothing set aside -- also no simulated
+# candidate (`sim_islands`: the skip in the simulate branch of replay_engine).
+ISLAND_STEPS = {'default14_wild_soft': dict(island_steps=[103, 233], stopped_at=233)}
+
+
 def _check_counts(name, c):
     run = rr.Run(name)
-    # at most a couple of islanded solves set aside, and the bulk of the run replayed
-    assert c['islands'] <= 2 and c['steps'] >= 0.9 * run.steps - 1, (name, c)
+    want = ISLAND_STEPS.get(name, dict(island_steps=[], stopped_at=None))
+    assert c['island_steps'] == want['island_steps'] and c['stopped_at'] == want['stopped_at'] and c['sim_islands'] == [], (name, c)
+    last = run.steps if want['stopped_at'] is None else want['stopped_at']
+    assert c['steps'] == last - sum(1 for t in want['island_steps'] if t < last), (name, c)      # every other step was compared
     assert c['done'] >= 10, (name, c)
     if 'simulate' in name:
         assert c.get('sims', 0) >= 40, (name, c)
+    if c['obs']:      # (observations compared: the reduced layouts the REFERENCE returned were compared with them -- f3)
+        assert c.get('reduced', 0) >= 4, (name, c)
 
 
 @pytest.mark.parametrize('name', NAMES)
@@ -72,11 +84,11 @@ def test_runenv_on_emulation_build_replays_reference_run(emu_lib, name):
     """The drop-in API itself (pypownet_amd.environment.RunEnv: tuple of step(), exception classes and masks, reward list,
     process_game_over) against what the reference's RunEnv returned."""
     c = rr.replay_runenv(emu_lib, name, max_steps=150)
-    assert c['steps'] >= 110 and c['done'] >= 8 and c['islands'] <= 2, c
+    assert c['steps'] == min(150, rr.Run(name).steps) and c['done'] >= 8 and c['islands'] == 0, c      # (no run of this list holds an island step)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', RUNENV_NAMES)
 def test_gpu_runenv_replays_reference_run(name):
     c = rr.replay_runenv(None, name)
-    assert c['steps'] >= 0.9 * rr.Run(name).steps - 1 and c['islands'] <= 2, c
+    assert c['steps'] == rr.Run(name).steps and c['islands'] == 0, c

@@ -415,6 +415,13 @@ def run_scenario(name):
             out['step_' + k] = np.asarray([st[k] for st in state_step])
             out['after_' + k] = np.asarray([state_after[t][k] for t in ended]).reshape((len(ended),) + np.shape(initial[k]))
     out['init_obs'] = np.asarray(initial_obs, dtype=np.float64)
+    # the reduced layouts, from the reference's OWN methods (environment.py:529-530, 597-601: Observation.as_minimalist() /
+    # as_ac_minimalist(), each .as_array()): the first sampled observations that exist, through array_to_observation
+    red = [k for k in sampled if not np.isnan(rec['obs'][k]).all()][:8]
+    out['reduced_steps'] = np.asarray(red, dtype=np.int32)
+    objs = [env.observation_space.array_to_observation(rec['obs'][k]) for k in red]
+    out['obs_minimalist'] = np.asarray([np.asarray(o.as_minimalist().as_array(), dtype=np.float64) for o in objs])
+    out['obs_ac_minimalist'] = np.asarray([np.asarray(o.as_ac_minimalist().as_array(), dtype=np.float64) for o in objs])
     if spec.get('simulate'):
         out['sim_step'] = np.asarray(sim['step'], dtype=np.int32)
         out['sim_action'] = np.packbits(np.asarray(sim['action'], dtype=np.uint8).reshape(len(sim['step']), -1), axis=1)

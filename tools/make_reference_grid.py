@@ -2,8 +2,11 @@
 """Turns a plain MATPOWER/PYPOWER case (.py or .json) into a pypownet reference grid: what the reference's tooling does
 (parameters/make_reference_grid.py:9-64) -- rows sorted, bus ids renumbered 1..n, one artificial twin busbar "666<id>"
 per substation (type 4, no load), every production and line in service, angles zeroed, baseKV defaulted to 100 when the
-case has none -- written as the JSON case format of this repository (pypownet_amd.case.load_case_file).
-SURVEY.md 8f rank 4 (case tooling; not on the hot path).  Usage: python tools/make_reference_grid.py case.py [out.json]"""
+case has none -- written in the source's own format like the reference's savecase (a PYPOWER ``reference_grid.py`` for a
+``.py`` case: what ``parameters/<env>/<level>/`` ships and ``loadcase`` reads, grid.py:65) or, for a ``.json`` source or an
+explicit ``out.json``, as the JSON case format of this repository's fixtures.  (MATPOWER ``.m`` is the Octave backend's format: out of
+scope with that backend.)  SURVEY.md 8f rank 4 (case tooling; not on the hot path).
+Usage: python tools/make_reference_grid.py case.py|case.json [out.py|out.json]"""
 import os
 import sys
 
@@ -11,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT)
-from pypownet_amd.case import load_case_file, save_case_json  # noqa: E402
+from pypownet_amd.case import load_case_file, save_case_json, save_case_py  # noqa: E402
 
 ARTIFICIAL_NODE_STARTING_STRING = '666'      # pypownet/__init__.py
 
@@ -46,6 +49,6 @@ if __name__ == '__main__':
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     src = sys.argv[1]
-    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(src), 'reference_grid.json')
-    save_case_json(make_reference_grid(load_case_file(src)), out)
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(src), 'reference_grid.' + src.rsplit('.', 1)[-1])
+    (save_case_py if out.endswith('.py') else save_case_json)(make_reference_grid(load_case_file(src)), out)
     print(out)
