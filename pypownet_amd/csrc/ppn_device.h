@@ -334,8 +334,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   o = (o + 15) & ~(size_t)15;
   PPN_TAKE(qrel, u16, NB * 2)
   PPN_TAKE(vc, double, 2 * NB * 8) PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(zero, double, 32)
-  S.tinv = nullptr;
-  if (!NT) { PPN_TAKE(tinv, double, 2 * PPN_TAIL_BUSES * PPN_TAIL_BUSES * 8) }
+  S.tinv = nullptr;      // (until round 3: the inverses of the fast-decoupled tails; they live in registers now)
   const size_t r0 = o;
   S.lu = (double*)(base + r0);
   S.amps = (double*)(base + r0);
