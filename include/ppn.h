@@ -236,7 +236,8 @@ int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* c
  * chain, the first step of a fresh episode, instead of the tail of the longest chain of the launch, a cascade that ended in a
  * diverging solve).  Anything that looks at the state in between (ppn_sync, ppn_read of a non-report field, ppn_write,
  * ppn_read_observation, a step in another mode, ...) settles the owed restarts first, so callers observe exactly what
- * auto_reset = 1 would have shown them. */
+ * auto_reset = 1 would have shown them.  Report fields (read without settling: a restart does not touch them): PPN_F_DONE, FLAG,
+ * ILLEGAL, ILLEGAL_COUNTS, ACTION_SWITCHES, REWARD, CASCADE_DEPTH, LINE_EVENTS, SOLVE_OUTCOME, N_STEPS, RETURN. */
 int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
              int32_t auto_reset);
 /* Open-loop rollout: n_steps consecutive Game.step calls of every environment in ONE launch, for callers whose actions do not

@@ -1404,6 +1404,7 @@ extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int
   {   // the report of the last step is what it is; everything else shows the restarted episode
     const bool report = f == PPN_F_DONE || f == PPN_F_FLAG || f == PPN_F_ILLEGAL || f == PPN_F_REWARD || f == PPN_F_ILLEGAL_COUNTS ||
                         f == PPN_F_ACTION_SWITCHES || f == PPN_F_CASCADE_DEPTH || f == PPN_F_LINE_EVENTS || f == PPN_F_SOLVE_OUTCOME ||
+                        f == PPN_F_N_STEPS || f == PPN_F_RETURN /* counters of EXECUTED steps: a restart does not touch them */ ||
                         (int)f == 100 /* phase counters of the profiling build */;
     if (!report && from_simulation == 0) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   }
