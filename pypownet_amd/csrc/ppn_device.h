@@ -269,7 +269,7 @@ struct DevState {
 // that have one (PQ buses: nv == 2).  A PV bus or the reference bus has no Q row, so its entries take no Q storage: qrel[i] is
 // the byte offset that turns entry index e of a row-i entry into its Q half ((char*)lu + qrel[i] + 16 e), 0xFFFF = no Q row.
 #ifndef PPN_TAIL_BUSES
-#define PPN_TAIL_BUSES 6          // multiple of 2, at most 8 (2 rows per bus in one DPP row of 16 lanes); IEEE-118: 6 (a tail of the last 5 levels) measured against 2 / 4 / 8
+#define PPN_TAIL_BUSES 8          // multiple of 2, at most 8 (2 rows per bus, 16 rows in a DPP row of 16 lanes per column block); until round 3: 6 (one row of 16 lanes held whole rows)
 #endif
 struct Smem {
   // across the step

@@ -243,7 +243,7 @@ def test_gpu_repacked_schedule(solver):
 
 @pytest.mark.parametrize('tail_buses', [6, 8])
 def test_gpu_dense_tail_unit(tail_buses):
-    """The register-resident dense tail on its own (tools/ubench/dense_tail_test.hip): tail_eliminate / tail_substitute of the kernel
+    """The register-resident dense tail on its own (tools/ubench/dense_tail_test.hip): the Gauss-Jordan sweep (tail_gj_steps) of the kernel
     sources on random systems of 2 .. 2 * tail_buses rows with identity rows, against Gaussian elimination on the host.  Holds the
     DPP hazard the engine tests cannot see at the shipped tail size (a copy the register allocator may place in front of a DPP
     read): found with a 16-row tail."""

@@ -1,4 +1,4 @@
-// Unit test of the register-resident dense tail (tail_eliminate / tail_substitute, ppn_solve.inc) on the GPU: random
+// Unit test of the register-resident dense tail (tail_gj_steps, ppn_solve.inc: Gauss-Jordan sweep, column blocks per DPP row) on the GPU: random
 // diagonally dominant systems of `rows` <= M rows, identity rows marked as in the solver, against Gaussian elimination on
 // the host.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DPPN_TAIL_BUSES=8] tools/ubench/dense_tail_test.hip -o build/dense_tail_test
 #include <hip/hip_runtime.h>
@@ -11,35 +11,34 @@
 #include "../../pypownet_amd/csrc/ppn_solve.inc"
 
 constexpr int M = PPN_TAIL_ROWS;
+// lane = 16 q + r: row r, columns 4q .. 4q + 3 (the layout of dense_tail, ppn_solve.inc)
 __global__ void k_tail(const double* A, const double* b, double* x, int rows, unsigned idrows) {
   const int lane0 = threadIdx.x;
   const int sys = blockIdx.x;
-  double ta[M]; double ty, tinv = 1.0;
-  {
-    const int lane = lane0;
-    for (int j = 0; j < M; ++j) ta[j] = (lane < rows && j < rows) ? A[((size_t)sys * M + lane) * M + j] : 0.0;
-    ty = lane < rows ? b[(size_t)sys * M + lane] : 0.0;
-  }
-  tail_eliminate<0, M>(ta, ty, tinv, rows, idrows, lane0);
-  tail_substitute<M - 1, M>(ta, ty, tinv, rows, idrows, lane0);
-  if (lane0 < rows) x[(size_t)sys * M + lane0] = ty;
+  const int r = lane0 & 15, q = lane0 >> 4;
+  double ta[4]; double ty, rs = 1.0;
+  for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; ta[j] = (r < rows && c < rows && c < M) ? A[((size_t)sys * M + r) * M + c] : 0.0; }
+  ty = r < rows ? b[(size_t)sys * M + r] : 0.0;
+  tail_gj_steps<0, M>(ta, ty, rs, rows, idrows, lane0);
+  if (lane0 < rows) x[(size_t)sys * M + lane0] = ty * rs;
 }
 
-// timing: the same elimination + substitution 64 times back to back on one wave (results chained through ty)
+// timing: the same sweep 64 times back to back on one wave (results chained through ty)
 __global__ void k_tail_time(const double* A, const double* b, double* x, long long* clk, int rows, unsigned idrows) {
   const int lane0 = threadIdx.x;
-  double a0[M]; double ty, tinv = 1.0, y0;
-  for (int j = 0; j < M; ++j) a0[j] = (lane0 < rows && j < rows) ? A[(size_t)lane0 * M + j] : 0.0;
-  y0 = lane0 < rows ? b[lane0] : 0.0;
+  const int r = lane0 & 15, q = lane0 >> 4;
+  double a0[4]; double ty, rs = 1.0, y0;
+  for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; a0[j] = (r < rows && c < rows && c < M) ? A[(size_t)r * M + c] : 0.0; }
+  y0 = r < rows ? b[r] : 0.0;
   ty = y0;
   const long long t0 = clock64();
   for (int rep = 0; rep < 64; ++rep) {
-    double ta[M];
-    for (int j = 0; j < M; ++j) ta[j] = a0[j] + 1e-300 * ty;
+    double ta[4];
+    for (int j = 0; j < 4; ++j) ta[j] = a0[j] + 1e-300 * ty;
     ty = y0 + 1e-300 * ty;
-    tinv = 1.0;
-    tail_eliminate<0, M>(ta, ty, tinv, rows, idrows, lane0);
-    tail_substitute<M - 1, M>(ta, ty, tinv, rows, idrows, lane0);
+    rs = 1.0;
+    tail_gj_steps<0, M>(ta, ty, rs, rows, idrows, lane0);
+    ty *= rs;
   }
   const long long t1 = clock64();
   if (lane0 < rows) x[lane0] = ty;
@@ -56,7 +55,7 @@ int main() {
     for (int rows = M; rows >= M - 2; rows -= 2) for (unsigned idr : {0u, 0x2u | 0x80u}) {
       hipLaunchKernelGGL(k_tail_time, dim3(1), dim3(64), 0, 0, dA, db, dx, dc, rows, idr);
       hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
-      printf("timing: M %d rows %2d identity rows 0x%04x: %lld clocks per elimination + substitution\n", M, rows, idr, c);
+      printf("timing: M %d rows %2d identity rows 0x%04x: %lld clocks per Gauss-Jordan sweep\n", M, rows, idr, c);
     }
     hipFree(dA); hipFree(db); hipFree(dx); hipFree(dc);
   }
