@@ -143,7 +143,7 @@ PPN_DEV double ppn_keep_if_bit(double x, unsigned m, int bit) {
 #define PROF_BEGIN() long long t_prof_ = clock64()
 #define PROF_MARK(E_, id) do { const long long t2_ = clock64(); if (lane0 == 0) (E_).prof[id] += t2_ - t_prof_; t_prof_ = clock64(); } while (0)
 #define PROF_BODY_BEGIN() const long long pb_c_ = clock64(), pb_w_ = wall_clock64()
-#define PROF_BODY_END(E_) do { if (lane0 == 0) { (E_).prof[14] += clock64() - pb_c_; (E_).prof[15] += wall_clock64() - pb_w_; } } while (0)
+#define PROF_BODY_END(E_) do { if (lane0 == 0) { (E_).prof[14] += clock64() - pb_c_; (E_).prof[15] += wall_clock64() - pb_w_; (E_).prof[13] = pb_w_; } } while (0)      /* [13]: when the body began (100 MHz wall ticks): launch-order studies */
 #else
 #define PROF_BEGIN() ((void)0)
 #ifdef PPN_MARKS

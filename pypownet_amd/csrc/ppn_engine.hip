@@ -98,6 +98,11 @@ struct ppn_engine {
   double* d_obs = nullptr;
   u8* d_valid = nullptr;
   int* d_perm = nullptr;            // launch order of the step kernel
+  int* d_work = nullptr;            // position counter of the persistent step kernel (ppn_kernels.inc)
+  int resident_slots = 0;           // workgroups of the step kernel the GPU holds at once (CUs x environments per CU)
+  size_t resident_for = 0;          // ... computed for this LDS size
+  bool persistent = true;           // PPN_PERSISTENT=0: one workgroup per environment whatever the batch, as until round 3
+  int persistent_rounds = 4;        // ... persistent from this many environments per resident slot on (PPN_PERSISTENT_ROUNDS)
   bool order_launches = true;       // PPN_LAUNCH_ORDER=0 disables the loading-ordered launch (A/B measurements)
   int* d_ids = nullptr;     // scratch for ppn_reset: env ids, slots, t0 (3 * batch)
   ppn_rules rules;
@@ -152,7 +157,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
-    if (KIND == K_STEP || KIND == K_ROLLOUT) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
+    if (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_STEP_PERSIST) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
@@ -180,7 +185,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
 // the others only as NT = 0.
 template <int W, int KIND>
 static int launch_nt(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
-  constexpr bool solves = (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
+  constexpr bool solves = (KIND == K_STEP || KIND == K_STEP_PERSIST || KIND == K_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
   if (solves && e->newton) return launch_w<W, KIND, solves ? 1 : 0>(e, a, nblocks, timed);
   return launch_w<W, KIND, 0>(e, a, nblocks, timed);
 }
@@ -199,7 +204,7 @@ static int set_lds_attr(size_t bytes) {
   int rc = 0;
 #define PPN_ATTR(K, N) rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
   PPN_ATTR(K_STEP, 0) PPN_ATTR(K_STEP, 1) PPN_ATTR(K_GAMEOVER, 0) PPN_ATTR(K_GAMEOVER, 1) PPN_ATTR(K_RESET, 0) PPN_ATTR(K_RESET, 1)
-  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1)
+  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1) PPN_ATTR(K_STEP_PERSIST, 0) PPN_ATTR(K_STEP_PERSIST, 1)
 #undef PPN_ATTR
   return rc;
 }
@@ -400,6 +405,23 @@ static int step_kernel_occupancy(const ppn_engine* e) {
   hipError_t rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 1>, 64, e->lds_bytes)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 0>, 64, e->lds_bytes);
   return rc == hipSuccess ? n : -1;
+}
+#endif
+
+#ifndef PPN_EMU
+// workgroups of the step kernel resident at once: CUs x min(what the runtime computes, what the 1280-byte LDS granules allow --
+// the runtime's figure was one too high for a 23 248-byte build)
+static int resident_slots_of(ppn_engine* e) {
+  if (e->resident_for == e->lds_bytes && e->resident_slots > 0) return e->resident_slots;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) return 0;
+  const int occ = e->W == 1 ? step_kernel_occupancy<1>(e) : (e->W == 2 ? step_kernel_occupancy<2>(e) : step_kernel_occupancy<4>(e));
+  const int granules = (int)((e->lds_bytes + 1279) / 1280);
+  const int by_lds = granules > 0 ? 128 / granules : occ;
+  const int per_cu = std::max(1, std::min(occ > 0 ? occ : by_lds, by_lds));
+  e->resident_slots = cus * per_cu;
+  e->resident_for = e->lds_bytes;
+  return e->resident_slots;
 }
 #endif
 
@@ -710,6 +732,9 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   e->d_actions = dalloc<u8>(e, (size_t)batch * d.alen);
   e->d_valid = dalloc<u8>(e, batch);
   e->d_perm = dalloc<int>(e, batch);
+  e->d_work = dalloc<int>(e, 16);
+  { const char* v = getenv("PPN_PERSISTENT"); if (v && v[0] == '0') e->persistent = false; }
+  { const char* v = getenv("PPN_PERSISTENT_ROUNDS"); if (v && atoi(v) > 0) e->persistent_rounds = atoi(v); }
   { const char* v = getenv("PPN_LAUNCH_ORDER"); if (v && v[0] == '0') e->order_launches = false; }
   { const char* v = getenv("PPN_RESTART_PRIO"); if (v) e->restart_prio = (float)atof(v); }
   e->d_ids = dalloc<int>(e, (size_t)3 * batch);
@@ -1159,13 +1184,17 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
   a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = mode;
   a.n_steps = n_steps; a.action_step_stride = per_step_actions ? mat : 0;
   a.restart_prio = e->restart_prio;
+  int nblocks = e->batch;
 #ifndef PPN_EMU
   if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first
-    hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch);
+    const int slots_ = e->persistent ? resident_slots_of(e) : 0;
+    const bool pers = e->persistent && n_steps == 1 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)e->batch;      // (the throughput regime only: see K_STEP_PERSIST)
+    hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, pers ? e->d_work : (int*)nullptr, slots_);
     a.perm = e->d_perm;
+    if (pers) { a.work_counter = e->d_work; a.n_work = e->batch; nblocks = e->resident_slots; }
   }
 #endif
-  if (n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, true) : launch<K_STEP>(e, a, e->batch, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  if (n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, true) : (a.work_counter ? launch<K_STEP_PERSIST>(e, a, nblocks, true) : launch<K_STEP>(e, a, nblocks, true))) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   if (a.auto_reset && e->maybe_dead) {
     // environments that were already over when the step began (after ppn_reset or after steps without auto_reset) did
     // not step; they are restarted by this post-pass.  Environments that end DURING a step restart inside the step

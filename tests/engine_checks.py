@@ -575,7 +575,7 @@ def check_reduced_observation_layouts(lib_path, envname='default118', steps=4, b
 
 
 def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='newton', bench_limits=False, max_active_buses=None,
-                             game_over_mode='soft', conf=None):
+                             game_over_mode='soft', conf=None, auto_reset=True):
     """Lock-step with the C oracle at BASELINE.json's full batch sizes (configs[1]: default14 Newton x 1024 environments,
     configs[2]: default118 Newton x 4096 environments with the cascade limits): do-nothing agent, environment e plays
     chronic (e mod n) from row (37 e) mod T, auto game-over reset.  Flags, line status, counters, chronic
@@ -600,7 +600,7 @@ def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='new
     act = np.zeros((batch, case.action_length), dtype=np.uint8)
     worst, n_done = 0.0, 0
     for t in range(steps):
-        eng.step(act, auto_reset=True)
+        eng.step(act, auto_reset=auto_reset)      # (2: the deferred restart of bench.py; the oracle restarts at once)
         orc.step(act, auto_reset=True)
         n_done += int(orc.read('DONE').sum())
         if (t + 1) % every and t + 1 != steps:

@@ -79,6 +79,27 @@ def test_gpu_full_size_default118_4096_bench_workload():
     assert st['done'] > 4096 and st['solves'] > 4096 * 60
 
 
+def test_gpu_persistent_step_kernel(monkeypatch):
+    """The PERSISTENT form of the step kernel (K_STEP_PERSIST: as many workgroups as the GPU holds, each taking the next position
+    of the launch order from a counter; the engine uses it from 4 environments per resident slot on -- 8192 environments and more
+    on this workload) in lock-step with the C oracle: forced on at 4096 environments (PPN_PERSISTENT_ROUNDS=1: 1792 workgroups play
+    4096 environments), Newton and fast-decoupled, and for the four-word kernels under random node splitting."""
+    monkeypatch.setenv('PPN_PERSISTENT_ROUNDS', '1')
+    st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 30, 10, bench_limits=True, max_active_buses=118, auto_reset=2)
+    assert st['done'] > 2048 and st['solves'] > 4096 * 30
+    st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 12, 6, solver='fdxb', bench_limits=True, max_active_buses=118)
+    assert st['solves'] > 4096 * 12
+    st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 15, 2048, 'newton', seed=909, obs_every=8)
+    assert st['split_buses'] > 0
+
+
+def test_gpu_persistent_kernel_is_the_one_running_at_8192():
+    """... and unforced: at 8192 environments the engine picks the persistent form by itself (kernel time per launch is recorded for
+    the step kernel whichever form ran; the lock-step is what matters)."""
+    st = ec.check_full_size_lockstep(HIP, 'default118', 8192, 10, 5, bench_limits=True, max_active_buses=118, auto_reset=2)
+    assert st['solves'] > 8192 * 10
+
+
 def test_gpu_full_size_default118_4096_fdxb():
     """configs[2] with the solver the reference itself runs (PF_ALG = 2, grid.py:63) at the full batch."""
     st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 30, 10, solver='fdxb', bench_limits=True, max_active_buses=118)
