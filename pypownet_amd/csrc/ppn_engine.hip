@@ -1188,7 +1188,9 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
 #ifndef PPN_EMU
   if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first
     const int slots_ = e->persistent ? resident_slots_of(e) : 0;
-    const bool pers = e->persistent && n_steps == 1 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)e->batch;      // (the throughput regime only: see K_STEP_PERSIST)
+    // (the throughput regime only: see K_STEP_PERSIST; not for the one-word kernels -- an IEEE-14 step is ~40 us, the trip to the
+    //  position counter between two of them costs more than the workgroup launch it replaces: 37.9 vs 36.8 M at 16384)
+    const bool pers = e->persistent && e->W >= 2 && n_steps == 1 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)e->batch;
     hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, pers ? e->d_work : (int*)nullptr, slots_);
     a.perm = e->d_perm;
     if (pers) { a.work_counter = e->d_work; a.n_work = e->batch; nblocks = e->resident_slots; }

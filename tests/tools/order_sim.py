@@ -26,12 +26,15 @@ def prof():
     return o
 
 
-def makespan(order, w):
+def makespan(order, w, starts=None):
     free = [0.0] * SLOTS
     heapq.heapify(free)
     end = 0.0
     for e in order:
-        t = heapq.heappop(free) + w[e]
+        t0_ = heapq.heappop(free)
+        if starts is not None:
+            starts.append(t0_)
+        t = t0_ + w[e]
         end = max(end, t)
         heapq.heappush(free, t)
     return end
@@ -75,6 +78,10 @@ for rep in range(steps + 1):
         globals()['SLOTS'] = 32 * 6
         res['current key, 8 XCD queues, 6 slots per CU'][-1] = max(makespan(order[x::8], w) for x in range(8))
         globals()['SLOTS'] = SL
+        sim_starts = []
+        makespan(order, w, sim_starts)
+        ssim = np.sort(np.asarray(sim_starts))
+        print('   step %d: the greedy replay would start #2500 at %.0f us, #3500 at %.0f, the last at %.0f' % (rep, ssim[2499], ssim[3499], ssim[-1]))
         st = (o[:, 13] - o[:, 13].min()) * 1e-2
         res.setdefault('measured: last body end - first body begin', []).append(float((st + w).max()))
         res.setdefault('measured: longest body', []).append(float(w.max()))
