@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 NAMES = ['connectivity (adjacency + BFS)', 'schedule check (+rebuild)', 'live buses/injections/types', 'Ybus', 'mismatch+Jacobian', 'LU factor', 'LU backward',
          'update/other', 'pfsoln+outputs', 'action+advance', 'cascade total (incl 0-8)', 'restart of ended episodes (incl its solves)',
-         'cut flags + topology write-back', 'results into LDS / registers, NaN test (per solve)']
+         'cut flags + topology write-back', '(slot 13: body start time)']
 
 
 def main():
@@ -66,8 +66,8 @@ def main():
     nsolve, nit = float(s1 - s0), float(i1 - i0)
     print('B=%d steps=%d solves=%d iterations=%d' % (B, steps, nsolve, nit))
     for k, name in enumerate(NAMES):
-        if k == 13 and tot[k] == 0:
-            continue       # (builds before round 4 have no such phase)
+        if k == 13:
+            continue       # (slot 13: wall time at which the body began -- tests/tools/chain_lengths.py, order_sim.py)
         unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
         per = tot[k] / {'iteration': nit, 'env-step': float(B * steps), 'solve': nsolve}[unit]
         print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
