@@ -363,6 +363,10 @@ def main():
     case, conf, chronics = load_workload()
     limits = bench_limits(case)
     B = args.batch
+    # the HIP events that bracket a step launch (roofline.avg_kernel_ms) cost ~7 us of stream time each pair -- 2 % of a step: the
+    # engine brackets every 4th launch of the timed region only (every launch when K is small); `value` is wall-clock over all K
+    timing_every = int(os.environ.get('PPN_KERNEL_TIMING_EVERY', '4' if args.steps >= 16 else '1'))
+    os.environ['PPN_KERNEL_TIMING_EVERY'] = str(timing_every)
     eng = Engine(case, conf, B, device=local_rank, chronics=chronics, thermal_limits=limits, max_active_buses=case.nS,
                  lu_capacity=int(os.environ.get('PPN_BENCH_LU_CAPACITY', '0')))   # (occupancy experiments only)
     slots, t0 = env_assignment(rank * B, B, chronics)
@@ -494,6 +498,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
                          'kernel': 'ppn_kernel<W=2,K_STEP>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
+                         'kernel_timing': 'HIP events on the engine stream around every %d%s step launch of the timed region: %d launches' % (
+                             timing_every, 'th' if timing_every > 1 else 'st', int(klaunch)),
                          'algorithmic_bytes_per_env_step': b_step,
                          # the compulsory state I/O alone (an LDS-resident solver legitimately moves fewer bytes
                          # than the streaming model; traffic / achieved bytes shows it)
