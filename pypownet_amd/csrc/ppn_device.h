@@ -24,6 +24,7 @@ struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LD
 #define LANE_LOOP for (int lane = 0; lane < 64; ++lane)
 #define WSYNC() ((void)0)
 #define WSYNC_G() ((void)0)
+#define PPN_SCHED_FENCE() ((void)0)
 // per-lane variables that live across LANE_LOOP regions (registers on the GPU)
 #define PPN_OPAQUE_S(x) (x)
 #define PPN_OPAQUE_V(x) (x)
@@ -70,6 +71,7 @@ __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" :
 #define WSYNC() __asm__ volatile("" ::: "memory")
 #endif
 #define WSYNC_G() __syncthreads()
+#define PPN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)      // the instruction scheduler moves nothing across this point
 #define LANE_VAR(type, name) type name
 #define LANE_ARR(type, name, n) type name[n]
 #define LV(name) name

@@ -80,6 +80,7 @@ def main():
         return
     for k, name in ((16, 'LU level bounds + record prefetch'), (17, 'LU phase 0 (invert, y\')'), (18, 'LU phase 1 (U\', forward)'), (19, 'LU phase 2 (Schur)')):
         print('%-28s total %.3e cyc  %8.0f cyc per iteration' % (name, tot[k], tot[k] / nit))
+    print('%-28s total %.3e cyc  %8.0f cyc per iteration' % ('dense tail (inside LU factor)', tot[30], tot[30] / nit))
     for k, name in ((20, 'evaluation pass 0 (V, clears)'), (21, 'evaluation pass 1 (Ybus entries)'), (22, 'evaluation pass 2 (buses, norm)')):
         print('%-28s total %.3e cyc  %8.0f cyc per evaluation (iterations + solves)' % (name, tot[k], tot[k] / (nit + nsolve)))
     if split:
