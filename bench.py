@@ -92,7 +92,7 @@ def env_assignment(first, count, chronics):
     return slots, t0
 
 
-def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
+def cpu_baseline(case, conf, chronics, limits, budget_s=12.0):
     """C oracle (oracle/ppn_oracle.c, OpenMP over environments) on a bounded sample of the same workload."""
     import subprocess
     from harness import oracle_engine            # tests/harness.py: the checker library is driven from outside the product
@@ -119,9 +119,8 @@ def cpu_baseline(case, conf, chronics, limits, budget_s=15.0):
         if el > budget_s or steps >= 4000:
             break
     out = {'value': nb * steps / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-           'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle with OpenMP over envs' % (nb, steps, el),
-           'note': 'UNOPTIMISED port: the checker (row-wise LU with a dense accumulator, symbolic work redone in every solve), '
-                   'not a KLU-class refactorising CPU solver -- the GPU / CPU ratio says nothing about kernel quality'}
+           'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle, OpenMP over envs' % (nb, steps, el),
+           'note': 'unoptimised checker port (symbolic work redone per solve): the GPU/CPU ratio is not a quality measure'}
     # the "reference-equivalent Python backend" -- the numpy/scipy restatement of the PYPOWER path
     # (scipy.sparse + SuperLU, the library class the reference uses), one environment on one host core, same workload
     try:
@@ -268,6 +267,12 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
     return out
 
 
+# keys of the flat `other_configs` map of the bench line, in the order other_configs() returns its entries: <key>_Msteps (M env-steps/s),
+# <key>_frac (roofline fraction on the entry's own SURVEY.md 8d byte count), <key>_kernel_ms (step kernel, HIP events)
+OTHER_CONFIG_KEYS = ['cfg1_d14_nr_b1024', 'cfg1_d14_nr_b16384', 'cfg2_d118_fdxb_b4096', 'cfg3_d118_nr_b32768',
+                     'cfg4_split_b1024_safe', 'cfg4_split_b1024_tuned', 'cfg4_split_b8192_tuned', 'cfg2_rule110_b4096']
+
+
 def other_configs(device, auto_reset, steps):
     """BASELINE.json configs[1], configs[2] with the reference's solver, the one-GPU share of configs[4], the large-batch point
     and the SURVEY.md 8d limit rule of configs[2] -- one entry each in the bench line (`other_configs`)."""
@@ -391,31 +396,41 @@ def main():
     if args.single_controller and use_dist:
         dev = 'cuda:%d' % local_rank
         all_actions = [torch.zeros_like(actions) for _ in range(world)] if rank == 0 else None   # the controller's choice
-        d_done = torch.empty((B,), dtype=torch.uint8, device=dev)
-        d_flag = torch.empty((B,), dtype=torch.int32, device=dev)
-        d_rew = torch.empty((B, 5), dtype=torch.float64, device=dev)
-        gathered = [torch.empty((B, 3), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
-
         on_host = backend != 'nccl'      # (gloo smoke mode: the collectives run on host copies)
         if on_host and rank == 0:
             all_actions = [t_.cpu() for t_ in all_actions]
-            gathered = [t_.cpu() for t_ in gathered]
+
+        # one [B x 3] report row block per step (PPN_F_STEP_REPORT: done, flag, reward sum -- written by the step kernel's epilogue),
+        # stream waits instead of host synchronisations, two buffer sets alternating: the host only enqueues, step t + 1's scatter is
+        # queued while step t's gather is in flight (round 4: two host synchronisations + three reads + a pack per step)
+        ext = torch.cuda.ExternalStream(eng.stream_ptr(), device=dev)
+        xb = [dict(act=torch.zeros_like(actions), res=torch.zeros((B, 3), dtype=torch.float64, device=dev),
+                   out=([torch.empty((B, 3), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None)) for _ in range(2)]
+        if on_host and rank == 0:
+            for b_ in xb:
+                b_['out'] = [t_.cpu() for t_ in b_['out']]
+        turn = [0]
 
         def exchange():
+            b_ = xb[turn[0]]
+            turn[0] ^= 1
+            cur = torch.cuda.current_stream()
             if on_host:
                 recv = torch.empty(actions.shape, dtype=actions.dtype)
                 dist.scatter(recv, all_actions, src=0)
-                actions.copy_(recv)
+                b_['act'].copy_(recv)
             else:
-                dist.scatter(actions, all_actions, src=0)            # [B x action_length] u8 to every rank
-            torch.cuda.synchronize()
-            eng.step_device(aptr, auto_reset=AUTO_RESET)
-            eng.read_into_device('DONE', d_done.data_ptr(), d_done.numel())
-            eng.read_into_device('FLAG', d_flag.data_ptr(), 4 * d_flag.numel())
-            eng.read_into_device('REWARD', d_rew.data_ptr(), 8 * d_rew.numel())
-            eng.sync()
-            res = torch.stack([d_done.double(), d_flag.double(), d_rew.sum(dim=1)], dim=1)
-            dist.gather(res.cpu() if on_host else res, gathered, dst=0)      # 24 B per environment back to the controller
+                cur.wait_stream(ext)
+                dist.scatter(b_['act'], all_actions, src=0)            # [B x action_length] u8 to every rank
+            ext.wait_stream(cur)
+            eng.step_device(b_['act'].data_ptr(), auto_reset=AUTO_RESET)
+            eng.read_into_device('STEP_REPORT', b_['res'].data_ptr(), 24 * B)
+            if on_host:
+                eng.wait()
+                dist.gather(b_['res'].cpu(), b_['out'], dst=0)
+            else:
+                cur.wait_stream(ext)
+                dist.gather(b_['res'], b_['out'], dst=0)      # 24 B per environment back to the controller
         exchange()
 
     eng.sync()
@@ -469,6 +484,12 @@ def main():
         pmc = pmc_summary(B)
         flop_step = solves_per_step * iters_per_solve * FLOP_PER_NR_ITERATION
         tflops = per_launch * flop_step / avg_kernel_s / 1e12 if avg_kernel_s > 0 else None
+        sq = (pmc or {}).get('sq_shares_of_wave_cycles') or {}
+        persistent_form = B >= 4 * 1792          # (ppn_engine.hip: the persistent form of the step kernel from 4 environments per resident slot on)
+        # NOTE on the shape of this line: the driver's parser keeps scalars one level deep and cuts strings at ~130 characters
+        # (round 4: nested dicts, lists and the long `other_configs` entries were dropped) -- everything below is flat and short;
+        # the long form of the side measurements goes to PPN_BENCH_DETAILS (default gpurun_out/bench_details.json when that
+        # directory exists) and into DESIGN.md section 5
         out = {
             'metric': 'env steps/sec, batched IEEE-118 AC load-flow',
             'value': total_steps / elapsed,
@@ -482,11 +503,9 @@ def main():
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic: IEEE-118 case + reference chronic series (fixture), synthetic thermal limits',
-            'config': {'workload': 'default118 AC Newton-Raphson (tol 1e-6), batch=%d envs/GPU with cascading-failure '
-                                   'inner loop, do-nothing agent, auto game-over reset' % B,
+            'config': {'workload': 'default118 AC Newton (tol 1e-6), %d envs/GPU, cascade loop, do-nothing agent, auto reset' % B,
                        'batch_per_gpu': B, 'solver': 'newton',
-                       'parallelism': ('env-sharded x%d, single controller: RCCL scatter of actions + gather of done/flag/'
-                                       'reward every step' if exchange is not None else
+                       'parallelism': ('env-sharded x%d, single controller: RCCL scatter actions + gather report per step' if exchange is not None else
                                        'env-sharded x%d, no collective in the step loop') % world,
                        'solves_per_step': solves_per_step, 'iters_per_solve': iters_per_solve,
                        'lds_bytes_per_env': eng.lds_bytes, 'envs_done_at_end': done_now, 'auto_reset_mode': AUTO_RESET,
@@ -497,25 +516,27 @@ def main():
                        'mean_cascade_depth_last_step': depth_now},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
-                         'kernel': 'ppn_kernel<W=2,K_STEP>', 'avg_kernel_ms': 1e3 * avg_kernel_s,
-                         'kernel_timing': 'HIP events on the engine stream around every %d%s step launch of the timed region: %d launches' % (
+                         # `traffic` is NOT measured in this run (counters cannot be collected from inside the timed run): it is the
+                         # rocprofv3 PMC pass of this build committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE per launch)
+                         'traffic_source': (pmc or {}).get('file'),
+                         'kernel': 'ppn_kernel<W=2,%s,NT=1>' % ('K_STEP_PERSIST' if persistent_form else 'K_STEP'),
+                         'avg_kernel_ms': 1e3 * avg_kernel_s,
+                         'kernel_timing': 'HIP events on the engine stream, every %d%s step launch: %d launches' % (
                              timing_every, 'th' if timing_every > 1 else 'st', int(klaunch)),
                          'algorithmic_bytes_per_env_step': b_step,
                          # the compulsory state I/O alone (an LDS-resident solver legitimately moves fewer bytes
                          # than the streaming model; traffic / achieved bytes shows it)
                          'compulsory_io_bytes_per_env_step': B_IO,
                          'compulsory_io_frac': (per_launch * B_IO / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if avg_kernel_s > 0 else None,
-                         # what actually binds the kernel: FP64 vector issue.  useful flops = SURVEY.md 8d's 55 kflop per
-                         # Newton iteration x measured iterations; valu_busy = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the
-                         # committed PMC pass (None when no pass matches this batch)
-                         'fp64_issue': {'useful_flop_per_env_step': flop_step, 'achieved_tflops': tflops,
-                                        'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
-                                        'frac': (tflops / FP64_VECTOR_PEAK_TFLOPS) if tflops else None,
-                                        'sq_active_inst_any_frac': ((pmc or {}).get('sq_shares_of_wave_cycles') or {}).get('SQ_ACTIVE_INST_ANY'),
-                                        'sq_wait_any_frac': ((pmc or {}).get('sq_shares_of_wave_cycles') or {}).get('SQ_WAIT_ANY'),
-                                        'pmc_file': (pmc or {}).get('file')}},
+                         # what actually binds the kernel: the dependency chains of one wavefront per environment.  useful flops =
+                         # SURVEY.md 8d's 55 kflop per Newton iteration x measured iterations; SQ shares from the committed PMC pass
+                         'fp64_useful_flop_per_env_step': flop_step, 'fp64_achieved_tflops': tflops,
+                         'fp64_peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
+                         'fp64_frac': (tflops / FP64_VECTOR_PEAK_TFLOPS) if tflops else None,
+                         'sq_active_inst_any_frac': sq.get('SQ_ACTIVE_INST_ANY'), 'sq_wait_any_frac': sq.get('SQ_WAIT_ANY')},
             'cpu_baseline': None,
         }
+        details = {}
         if world == 1 and not args.no_rollout:
             # OPEN-LOOP rollout (ppn_rollout): the same K steps of the same do-nothing agent in ONE launch -- every environment
             # plays its K steps back to back instead of waiting, after every step, for the longest cascade of the batch.  Same
@@ -529,9 +550,29 @@ def main():
             eng.sync()
             el_r = time.perf_counter() - t_r
             r1 = int(eng.read('N_STEPS').astype(np.int64).sum())
-            out['config']['open_loop_rollout'] = {
-                'env_steps_per_s': (r1 - r0) / el_r, 'steps_per_launch': args.steps, 'env_steps_executed': r1 - r0,
-                'note': 'ppn_rollout: K steps per environment in one launch (open-loop agents only); not the headline'}
+            out['config']['open_loop_rollout_env_steps_per_s'] = (r1 - r0) / el_r      # (ppn_rollout, open-loop agents only; not the headline)
+        if world == 1 and exchange is None:
+            # CLOSED LOOP WITH THE OBSERVATION (what RunEnv.step returns, environment.py:848-866): the same step followed by the
+            # observation gather (K_OBS) into a device tensor, every step -- what a policy that lives on this GPU pays.  Full
+            # Observation.as_array() in float64 (4 967 values = 39.7 KB per environment) and the minimalist layout in float32.
+            for key, lay, f32 in (('closed_loop_with_observation_env_steps_per_s', 'full', False),
+                                  ('closed_loop_with_minimalist_f32_observation_env_steps_per_s', 'minimalist', True)):
+                n_obs = eng.observation_length(lay)
+                obs_t = torch.empty((B, n_obs), dtype=torch.float32 if f32 else torch.float64, device='cuda:%d' % local_rank)
+                nb = obs_t.numel() * obs_t.element_size()
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    eng.step_device(aptr, auto_reset=AUTO_RESET)
+                    eng.observations_into_device(obs_t.data_ptr(), nb, layout=lay, dtype=np.float32 if f32 else np.float64)
+                eng.sync()
+                c0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+                t_o = time.perf_counter()
+                for _ in range(args.steps):
+                    eng.step_device(aptr, auto_reset=AUTO_RESET)
+                    eng.observations_into_device(obs_t.data_ptr(), nb, layout=lay, dtype=np.float32 if f32 else np.float64)
+                eng.sync()
+                out['config'][key] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - c0) / (time.perf_counter() - t_o)
+                del obs_t
         if world == 1:
             # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
             # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`
@@ -544,15 +585,33 @@ def main():
                 eng.read('DONE'); eng.read('FLAG'); eng.read('REWARD')
             eng.sync()
             out['config']['host_boundary_env_steps_per_s'] = B * n_host / (time.perf_counter() - t_h)
-        if world == 1 and not args.no_other_configs and B == BATCH_PER_GPU:
+        if world == 1 and not args.no_other_configs and B == BATCH_PER_GPU and exchange is None:
             eng.close()
-            out['other_configs'] = other_configs(local_rank, AUTO_RESET, max(12, min(40, args.steps)))
+            long_form = other_configs(local_rank, AUTO_RESET, max(12, min(40, args.steps)))
+            details['other_configs'] = long_form
+            flat = {}
+            for key, entry in zip(OTHER_CONFIG_KEYS, long_form):
+                if 'error' in entry:
+                    flat[key + '_error'] = str(entry['error'])[:100]
+                    continue
+                flat[key + '_Msteps'] = round(entry['env_steps_per_s'] / 1e6, 4)
+                flat[key + '_frac'] = round(entry['roofline_frac'], 4)
+                flat[key + '_kernel_ms'] = round(entry['step_kernel_ms'], 4)
+            out['other_configs'] = flat
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(case, conf, chronics, limits)
             except Exception as ex:   # the baseline must never take the bench line down
                 out['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port',
                                        'sample': 'failed: %s' % ex}
+        dpath = os.environ.get('PPN_BENCH_DETAILS') or (os.path.join(ROOT, 'gpurun_out', 'bench_details.json')
+                                                        if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else None)
+        if dpath and details:
+            try:
+                with open(dpath, 'w') as f:
+                    json.dump(details, f, indent=1)
+            except OSError:
+                pass
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

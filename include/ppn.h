@@ -184,6 +184,9 @@ typedef enum ppn_field {
                                         PPN_RESTART_ATTEMPTS restarts in a row diverged as well (see ppn_process_game_over) */
   PPN_F_EPOCH,             /* i32 [1]   Game.epoch (game.py:333, 767): 1 after ppn_reset, + 1 for EVERY restart attempt of
                                         process_game_over -- the reference increments it on each recursive call too            */
+  PPN_F_STEP_REPORT,       /* f64 [3]   (done, flag, sum of the five reward components) of the last step in ONE row: what a single
+                                        controller gathers from every shard per step (<= 24 B per environment) -- one
+                                        stream-ordered device copy instead of three reads + a pack (libppn 0.2)                  */
   PPN_F_COUNT
 } ppn_field;
 
@@ -257,6 +260,27 @@ int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, i
  * check_rollout_dead_at_start pins the exception). */
 int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t n_steps,
                 int32_t per_step_actions, int32_t auto_reset);
+/* ---- closed-loop stepping without the batch barrier: policies that live on the device (libppn 0.2) -----------------------------
+ * A closed-loop agent decides from what the last step left.  When the decision rule itself runs on the device, no environment has
+ * to wait for the rest of the batch between its steps: ppn_rollout_policy plays n_steps closed-loop steps of every environment in
+ * ONE launch -- per step: the policy turns the environment's own state into an action, then Game.step (fused auto-reset: an
+ * episode that ends is restarted right behind its last step, so the next decision sees the fresh episode, as an agent behind
+ * RunEnv.step / process_game_over does, runner.py:81-96).  The steps are handed out one at a time, in environment order, to as
+ * many workgroups as the GPU holds: an environment's step s + 1 goes to whichever workgroup is free once its step s is complete.
+ * Same trajectories, bit for bit, as n_steps rounds of { ppn_policy_actions; ppn_step(actions, on device, auto_reset = 1) }
+ * (tests: check_policy_rollout_equals_stepping); what differs is the schedule -- a launch of 4096 environments no longer lasts
+ * n_steps times its longest cascade.  The built-in policies (a user policy is one more `case` in policy_action, ppn_game.inc):
+ *   PPN_POLICY_DO_NOTHING    the reference's DoNothing agent (agent.py:40-57)
+ *   PPN_POLICY_LINE_RELIEF   a toy operator: reconnect the first line that is out, reconnectable (timesteps_before_lines_
+ *                            reconnectable = 0) and not cooling down; else, if the most loaded line carries more than
+ *                            params[0] x its thermal limit and may be actioned, open it; else do nothing.  One line switch at
+ *                            most: legal by construction.
+ * ppn_policy_actions writes the policy's choice for the CURRENT state of every environment into a caller-owned DEVICE buffer
+ * u8 [batch x action_len] (restarts owed by a deferred auto-reset are settled first: the policy looks at the state). */
+#define PPN_POLICY_DO_NOTHING 0
+#define PPN_POLICY_LINE_RELIEF 1
+int ppn_policy_actions(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, uint8_t* actions_out_device);
+int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, int32_t n_steps);
 /* Topology-action search (the reference's search agents call RunEnv.simulate once per candidate,
  * pypownet/agent.py:161-325): candidate c forks the CURRENT state of environment env_ids[c] and plays
  * Game.simulate(actions[c]) on it (game.py:887-943); any number of candidates per environment, one kernel launch.
@@ -305,6 +329,9 @@ int ppn_runpf_batch(ppn_engine* e);
  * The state of environments 0..n-1 of the engine is overwritten (use an engine of its own for pure solves).
  * Host pointers only; the call synchronises. */
 typedef struct ppn_mpc_batch {
+  int32_t struct_size;                         /* = sizeof(ppn_mpc_batch) of the header the caller was built against: the library refuses
+                                                  (PPN_E_INVALID) a struct of another layout instead of reading its fields shifted
+                                                  (libppn 0.2; the 0.1 struct began with `n`) */
   int32_t n;
   int32_t bus_cols, gen_cols, branch_cols;     /* columns of the input arrays: >= 10 (MATPOWER writes 13), >= 8, >= 11 */
   int32_t bus_rows, gen_rows, branch_rows;     /* rows of ONE case in the arrays below: must be 2 nS, nP, nl of the engine's case --

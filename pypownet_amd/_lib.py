@@ -44,7 +44,7 @@ class PpnRules(C.Structure):
 class PpnMpcBatch(C.Structure):
     """ppn_mpc_batch (include/ppn.h): MATPOWER arrays of n cases in, result arrays out."""
     _dp = C.POINTER(C.c_double)
-    _fields_ = [('n', C.c_int32), ('bus_cols', C.c_int32), ('gen_cols', C.c_int32), ('branch_cols', C.c_int32),
+    _fields_ = [('struct_size', C.c_int32), ('n', C.c_int32), ('bus_cols', C.c_int32), ('gen_cols', C.c_int32), ('branch_cols', C.c_int32),
                 ('bus_rows', C.c_int32), ('gen_rows', C.c_int32), ('branch_rows', C.c_int32),
                 ('bus', _dp), ('gen', _dp), ('branch', _dp), ('bus_out', _dp), ('gen_out', _dp), ('branch_out', _dp),
                 ('success', C.POINTER(C.c_uint8)), ('outcome', C.POINTER(C.c_int32))]
@@ -62,9 +62,9 @@ FIELDS = ['VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMP
           'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN',
           'SOFT_COUNT', 'DONE', 'FLAG', 'ILLEGAL', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'CHRONIC_SLOT',
           'CHRONIC_ROW', 'N_LOADS_CUT', 'N_PRODS_CUT', 'SUCCESS', 'OBSERVATION', 'BUS_TYPE', 'REWARD', 'ILLEGAL_COUNTS',
-          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'RETURN', 'DEAD', 'EPOCH']
+          'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'RETURN', 'DEAD', 'EPOCH', 'STEP_REPORT']
 FIELD_ID = {k: i for i, k in enumerate(FIELDS)}
-_F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD', 'RETURN'}
+_F64 = {'VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT', 'AMPS', 'OBSERVATION', 'REWARD', 'RETURN', 'STEP_REPORT'}
 _U8 = {'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'LINES_STATUS', 'DONE', 'SUCCESS', 'BUS_TYPE',
        'LINE_EVENTS', 'DEAD'}
 
@@ -81,7 +81,8 @@ def field_dtype(name):
 EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limits', 'ppn_load_chronic', 'ppn_reset',
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
-           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays', 'ppn_rollout']
+           'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays', 'ppn_rollout',
+           'ppn_policy_actions', 'ppn_rollout_policy']
 
 
 def _preload_torch_hip_runtime():
@@ -172,6 +173,10 @@ def bind_signatures(lib, full_abi=True):
     if full_abi:
         lib.ppn_wait.argtypes = [vp]
         lib.ppn_wait.restype = C.c_int
+        lib.ppn_policy_actions.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_int32, vp]
+        lib.ppn_policy_actions.restype = C.c_int
+        lib.ppn_rollout_policy.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_int32]
+        lib.ppn_rollout_policy.restype = C.c_int
     lib.ppn_stream.argtypes = [vp]
     lib.ppn_stream.restype = vp
     lib.ppn_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -21,7 +21,30 @@ struct __attribute__((aligned(16))) ppn_d2 { double x, y; };   // one 16-byte LD
 
 #ifdef PPN_EMU
 #define PPN_DEV static inline
-#define LANE_LOOP for (int lane = 0; lane < 64; ++lane)
+// Lane order of the lane-serial build.  On the GPU the 64 lanes of a LANE_LOOP region run in lockstep, instruction by instruction;
+// the emulation runs one lane's whole region after the other, so a region in which one lane reads (or overwrites) an LDS / global
+// location that ANOTHER lane writes in the same region has a lane-order-dependent result here and an instruction-order-dependent
+// one on the GPU -- an ordering assumption nothing guarantees.  A correct region gives the same result in EVERY lane order (up to
+// the rounding of floating-point atomic sums, whose order the GPU does not fix either).  ppn_emu_set_lane_order (exported by the
+// emulation build only; tests/test_emu_lane_order.py): 0 ascending (default), 1 descending, >= 2 a fresh pseudo-random permutation
+// for every region, seeded with the value (VERDICT r04 #2a: the race-hunting mode of the emulation).
+static int ppn_emu_order_mode_ = 0;
+static unsigned ppn_emu_order_state_ = 1u;
+static unsigned char ppn_emu_perm_[64];
+static inline int ppn_emu_lane_of(int pos) {
+  if (ppn_emu_order_mode_ == 0) return pos;
+  if (ppn_emu_order_mode_ == 1) return 63 - pos;
+  if (pos == 0) {
+    for (int i = 0; i < 64; ++i) ppn_emu_perm_[i] = (unsigned char)i;
+    for (int i = 63; i > 0; --i) {
+      unsigned x = ppn_emu_order_state_; x ^= x << 13; x ^= x >> 17; x ^= x << 5; ppn_emu_order_state_ = x;
+      const int j = (int)(x % (unsigned)(i + 1));
+      const unsigned char t = ppn_emu_perm_[i]; ppn_emu_perm_[i] = ppn_emu_perm_[j]; ppn_emu_perm_[j] = t;
+    }
+  }
+  return ppn_emu_perm_[pos & 63];
+}
+#define LANE_LOOP for (int li_ = 0, lane = ppn_emu_lane_of(0); li_ < 64; lane = ppn_emu_lane_of(++li_ < 64 ? li_ : 63))
 #define WSYNC() ((void)0)
 #define WSYNC_G() ((void)0)
 #define PPN_SCHED_FENCE() ((void)0)
@@ -242,6 +265,8 @@ struct DevState {
   int *rec, *lcd, *ncd, *soft;     // counters
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
+  int* nbuild;                     // schedules this environment's own wavefront had to build inside a solve since ppn_reset (internal field 102: with the
+                                   // schedule pre-pass on, that is what the pre-pass did not foresee)
   int* nstep;                      // Game.step calls this environment has executed since ppn_reset (PPN_F_N_STEPS)
   u8* lev;                         // [nl] PPN_EV_* bits of the last step
   int* src;                        // outcome (SOLVE_*) of the last solve of the last step's cascade
@@ -251,6 +276,7 @@ struct DevState {
   long long* prof;                 // [32] cycle counters per phase (only written by -DPPN_PROF builds)
   double* reward;                  // [5] reward components of the last step
   double* ret;                     // sum of the reward components over the steps executed since ppn_reset (PPN_F_RETURN)
+  double* report;                  // [3] (done, flag, reward sum) of the last step, one row per environment (PPN_F_STEP_REPORT)
   int *illn, *actsw;               // [3] illegal-action counts, [2] node / line switches of the action after the step
   float* prio;                     // expected cost of the NEXT step (largest ampere flow / limit after this one): launch order
   // per-environment solve workspace (L2-resident, streamed sequentially by the numeric phases)
@@ -292,8 +318,9 @@ struct Smem {
   u64* adjF;                                   // schedule_build scratch (view of R, with adj0)
   u16 *yptr, *scn, *moffq, *toffq, *rowptr, *lvlp, *lvlm, *lvlt, *int2row, *ediag;
   u8 *pvl, *kq, *mem, *mown;
-  // compact carve only (is_action_valid)
+  // compact carve only (is_action_valid), schedule pre-pass
   u8* act;
+  int* scr;                           // schedule pre-pass only: exchange words of the workgroup-wide collectives (sb_scan_u16, sb_sum_i)
 };
 #define PPN_QNONE 0xFFFFu
 
@@ -318,6 +345,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   Smem& S = *Sp;
   size_t o = 0;
   const size_t NB = d.NB, nl = d.nl, nrows = d.nrows;
+  S.scr = nullptr;
 #define PPN_TAKE(field, type, bytes) S.field = (type*)(base + o); o += (((size_t)(bytes)) + 15) & ~(size_t)15;
   if (compact) {
     PPN_TAKE(rhs, double, 2 * NB * 8) PPN_TAKE(touched, u8, nrows) PPN_TAKE(subchg, u8, (size_t)d.nS) PPN_TAKE(act, u8, (size_t)d.alen)
@@ -367,4 +395,27 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   if (r0 + nl * 8 > o) o = r0 + nl * 8;
 #undef PPN_TAKE
   return (o + 15) & ~(size_t)15;
+}
+
+// LDS of the schedule pre-pass (K_SCHED): the node bits it builds for, the action, and schedule_build's scratch view -- nothing of
+// a solve.  (IEEE-118 with every busbar active: ~23 KB, seven four-wave workgroups per CU.)
+PPN_HD size_t ppn_carve_sched(const DevCase& d, int W, unsigned char* base, Smem* Sp) {
+  Smem& S = *Sp;
+  size_t o = 0;
+  const size_t NB = d.NB, nl = d.nl, nrows = d.nrows;
+#define PPN_TAKE(field, type, bytes) S.field = (type*)(base + o); o += (((size_t)(bytes)) + 15) & ~(size_t)15;
+  PPN_TAKE(scr, int, 64)
+  PPN_TAKE(act, u8, (size_t)d.alen) PPN_TAKE(subchg, u8, (size_t)d.nS)
+  PPN_TAKE(on, u8, nl) PPN_TAKE(en, u8, nl) PPN_TAKE(pn, u8, (size_t)d.nP) PPN_TAKE(ln, u8, (size_t)d.nL)
+  PPN_TAKE(touched, u8, nrows) PPN_TAKE(r2s, u8, nrows)
+  PPN_TAKE(lf, u8, nl) PPN_TAKE(lt, u8, nl)
+  PPN_TAKE(adj0, u64, NB * W * 8) PPN_TAKE(adjF, u64, NB * W * 8)
+  PPN_TAKE(yptr, u16, (NB + 1) * 2) PPN_TAKE(scn, u16, (nrows + 1) * 2) PPN_TAKE(moffq, u16, (NB + 1) * 2) PPN_TAKE(toffq, u16, (NB + 1) * 2)
+  PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
+  PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(ediag, u16, NB * 2)
+  PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
+#undef PPN_TAKE
+  S.st = nullptr; S.over = nullptr; S.amps = nullptr; S.nv = nullptr; S.qrel = nullptr; S.vc = nullptr; S.rhs = nullptr; S.zero = nullptr;
+  S.lu = nullptr; S.tinv = nullptr;
+  return o;
 }

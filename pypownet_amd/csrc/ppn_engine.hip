@@ -83,6 +83,8 @@ struct ppn_engine {
   hipStream_t stream = 0;
   size_t lds_bytes = 0;
   size_t lds_small = 0;       // compact carve of the kernels without a solve (K_VALID, K_OBS)
+  size_t lds_sched = 0;       // carve of the schedule pre-pass (ppn_carve_sched)
+  bool sched_prepass = true;  // PPN_SCHED_PREPASS=0: schedules are only ever built inside the step kernel, as until round 4
   // Q plane of the Newton storage (Smem): sized from the chronics unless rules.lu_capacity fixes the storage
   bool auto_qcap = true;
   std::vector<int> rowlen_sub, sub_gen_;   // filled-pattern row length of every substation's busbar, production of a substation (-1: none)
@@ -99,6 +101,7 @@ struct ppn_engine {
   u8* d_valid = nullptr;
   int* d_perm = nullptr;            // launch order of the step kernel
   int* d_work = nullptr;            // position counter of the persistent step kernel (ppn_kernels.inc)
+  int* d_progress = nullptr;        // ppn_rollout_policy: steps of the launch every environment has completed
   int resident_slots = 0;           // workgroups of the step kernel the GPU holds at once (CUs x environments per CU)
   size_t resident_for = 0;          // ... computed for this LDS size
   bool persistent = true;           // PPN_PERSISTENT=0: one workgroup per environment whatever the batch, as until round 3
@@ -155,7 +158,17 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   std::vector<unsigned char> lds(std::max(e->lds_bytes, e->lds_small) + 64);
   unsigned char* base = (unsigned char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
   Smem S;
-  ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS);
+  ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS || KIND == K_POLICY);
+  if (KIND == K_POLICY_ROLLOUT) {      // the items in their hand-out order: (step, environment)
+    for (int item = 0; item < a.n_work; ++item) {
+      const int s_ = item / a.n_envs, k_ = item - s_ * a.n_envs;
+      const int e_ = a.perm ? a.perm[k_] : k_;
+      memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));
+      policy_action<W>(a.d, a.st, a.policy, e_, a.policy_out + (size_t)e_ * a.d.alen, 0);
+      body_step<W, NT>(a.d, a.st, S, a.policy_out, 0, 1, a.restart_prio, e_, 0);
+    }
+    return 0;
+  }
   for (int env = 0; env < nblocks; ++env) {
     memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
     if (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_STEP_PERSIST) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
@@ -163,6 +176,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
     else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, 0);
+    else if (KIND == K_POLICY) body_policy<W>(a.d, a.st, a.policy, a.policy_out, env, 0);
     else if (KIND == K_OBS) { if (a.obs_f32) body_obs<float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0); }
   }
   if (timed) e->launches++;
@@ -179,8 +193,30 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     (void)hipEventRecord(e0, e->stream);
   }
-  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), (KIND == K_VALID || KIND == K_OBS) ? e->lds_small : e->lds_bytes, e->stream, a);
+  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), (KIND == K_VALID || KIND == K_OBS || KIND == K_POLICY) ? e->lds_small : e->lds_bytes, e->stream, a);
   if (timed) { (void)hipEventRecord(e1, e->stream); e->launches++; }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+#endif
+}
+
+// Schedule pre-pass of the engines whose busbars may split (body_sched, ppn_game.inc): warms every environment's schedule cache for
+// the topology its step is about to solve.
+template <int W>
+static int launch_sched(ppn_engine* e, const KArgs& a, int nblocks) {
+#ifdef PPN_EMU
+  std::vector<unsigned char> lds(e->lds_sched + 64);
+  unsigned char* base = (unsigned char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+  Smem S;
+  ppn_carve_sched(a.d, W, base, &S);
+  for (int env = 0; env < nblocks; ++env) {
+    memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, e->lds_sched);
+    if (e->newton) body_sched<W, PPN_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0);
+    else body_sched<W, PPN_FD_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0);
+  }
+  return 0;
+#else
+  if (e->newton) hipLaunchKernelGGL((ppn_sched_kernel<W, 1>), dim3(nblocks), dim3(PPN_SCHED_THREADS), e->lds_sched, e->stream, a);
+  else hipLaunchKernelGGL((ppn_sched_kernel<W, 0>), dim3(nblocks), dim3(PPN_SCHED_THREADS), e->lds_sched, e->stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
 }
@@ -189,7 +225,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
 // the others only as NT = 0.
 template <int W, int KIND>
 static int launch_nt(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
-  constexpr bool solves = (KIND == K_STEP || KIND == K_STEP_PERSIST || KIND == K_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
+  constexpr bool solves = (KIND == K_STEP || KIND == K_STEP_PERSIST || KIND == K_ROLLOUT || KIND == K_POLICY_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
   if (solves && e->newton) return launch_w<W, KIND, solves ? 1 : 0>(e, a, nblocks, timed);
   return launch_w<W, KIND, 0>(e, a, nblocks, timed);
 }
@@ -208,7 +244,7 @@ static int set_lds_attr(size_t bytes) {
   int rc = 0;
 #define PPN_ATTR(K, N) rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
   PPN_ATTR(K_STEP, 0) PPN_ATTR(K_STEP, 1) PPN_ATTR(K_GAMEOVER, 0) PPN_ATTR(K_GAMEOVER, 1) PPN_ATTR(K_RESET, 0) PPN_ATTR(K_RESET, 1)
-  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1) PPN_ATTR(K_STEP_PERSIST, 0) PPN_ATTR(K_STEP_PERSIST, 1)
+  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1) PPN_ATTR(K_STEP_PERSIST, 0) PPN_ATTR(K_STEP_PERSIST, 1) PPN_ATTR(K_POLICY_ROLLOUT, 0) PPN_ATTR(K_POLICY_ROLLOUT, 1) PPN_ATTR(K_POLICY, 0)
 #undef PPN_ATTR
   return rc;
 }
@@ -285,7 +321,11 @@ static inline void enter(const ppn_engine* e) {
 #endif
 }
 
-extern "C" const char* ppn_version(void) { return "pypownet_amd libppn 0.1 (gfx950)"; }
+#ifdef PPN_EMU
+// (emulation build only: lane order of the LANE_LOOP regions, see ppn_device.h)
+extern "C" void ppn_emu_set_lane_order(int mode) { ppn_emu_order_mode_ = mode; ppn_emu_order_state_ = (unsigned)mode * 2654435761u + 12345u; if (!ppn_emu_order_state_) ppn_emu_order_state_ = 1u; }
+#endif
+extern "C" const char* ppn_version(void) { return "pypownet_amd libppn 0.2 (gfx950)"; }
 
 extern "C" const char* ppn_last_error(const ppn_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -324,11 +364,11 @@ static int alloc_state(ppn_engine* e, DevState* s, size_t B) {
   s->flag = dalloc<int>(e, B); s->ill = dalloc<int>(e, B); s->depth = dalloc<int>(e, B);
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
-  s->nstep = dalloc<int>(e, B);
+  s->nstep = dalloc<int>(e, B); s->nbuild = dalloc<int>(e, B);
   s->prow = dalloc<int>(e, B); s->lev = dalloc<u8>(e, B * d.nl); s->src = dalloc<int>(e, B); s->draws = dalloc<unsigned>(e, B);
   s->prof = dalloc<long long>(e, B * 32);
   s->prio = dalloc<float>(e, B);
-  s->reward = dalloc<double>(e, B * 5); s->ret = dalloc<double>(e, B); s->illn = dalloc<int>(e, B * 3); s->actsw = dalloc<int>(e, B * 2);
+  s->reward = dalloc<double>(e, B * 5); s->ret = dalloc<double>(e, B); s->report = dalloc<double>(e, B * 3); s->illn = dalloc<int>(e, B * 3); s->actsw = dalloc<int>(e, B * 2);
   s->ws_tri = dalloc<u64>(e, B * d.TCAP); s->ws_pair = dalloc<u64>(e, B * d.MCAP);
   s->ws_piv = dalloc<unsigned>(e, B * d.NB);
   s->ws_cache = dalloc<u8>(e, B * (size_t)d.cache_stride);   // zero-filled: header.valid == 0
@@ -341,6 +381,9 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
   const DevCase& d = e->dc;
   if ((int)f == 100) {   /* phase cycle counters of -DPPN_PROF builds (tools/profile_phases.py) */
     fi->elem = sizeof(long long); fi->n = 32; fi->off = offsetof(DevState, prof); *writable = true; return true;
+  }
+  if ((int)f == 102) {   /* schedules built INSIDE a solve since the engine was created (what the schedule pre-pass did not foresee) */
+    fi->elem = sizeof(int); fi->n = 1; fi->off = offsetof(DevState, nbuild); *writable = false; return true;
   }
   if ((int)f == 101) {   /* raw schedule cache blobs (tools/fill_survey.py reads the headers: fill, records) */
     fi->elem = 1; fi->n = d.cache_stride; fi->off = offsetof(DevState, ws_cache); *writable = false; return true;
@@ -389,6 +432,7 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
     case PPN_F_RETURN: FI(ret, double, 1, false)
     case PPN_F_DEAD: FI(dead, u8, 1, false)
     case PPN_F_EPOCH: FI(epoch, int, 1, false)
+    case PPN_F_STEP_REPORT: FI(report, double, 3, false)
     default: return false;
   }
 #undef FI
@@ -404,10 +448,17 @@ extern "C" size_t ppn_field_bytes(const ppn_engine* e, ppn_field f) {
 
 #ifndef PPN_EMU
 template <int W>
-static int step_kernel_occupancy(const ppn_engine* e) {
+static int step_kernel_occupancy(const ppn_engine* e, bool persistent_form = false) {
   int n = 0;
-  hipError_t rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 1>, 64, e->lds_bytes)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 0>, 64, e->lds_bytes);
+  hipError_t rc;
+  // (the persistent form is a kernel symbol of its own -- a loop around the body, its own register allocation: the grid of that
+  //  launch is sized from ITS occupancy)
+  if (persistent_form)
+    rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP_PERSIST, 1>, 64, e->lds_bytes)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP_PERSIST, 0>, 64, e->lds_bytes);
+  else
+    rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 1>, 64, e->lds_bytes)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 0>, 64, e->lds_bytes);
   return rc == hipSuccess ? n : -1;
 }
 #endif
@@ -419,9 +470,11 @@ static int resident_slots_of(ppn_engine* e) {
   if (e->resident_for == e->lds_bytes && e->resident_slots > 0) return e->resident_slots;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) return 0;
-  const int occ = e->W == 1 ? step_kernel_occupancy<1>(e) : (e->W == 2 ? step_kernel_occupancy<2>(e) : step_kernel_occupancy<4>(e));
+  const int occ = e->W == 1 ? step_kernel_occupancy<1>(e, true) : (e->W == 2 ? step_kernel_occupancy<2>(e, true) : step_kernel_occupancy<4>(e, true));
   const int granules = (int)((e->lds_bytes + 1279) / 1280);
-  const int by_lds = granules > 0 ? 128 / granules : occ;
+  int lds_per_cu = 0;      // bytes of LDS a CU hands out, in granules of 1280 bytes (gfx950: 160 KiB = 128 granules)
+  if (hipDeviceGetAttribute(&lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, e->device) != hipSuccess || lds_per_cu <= 0) lds_per_cu = 160 * 1024;
+  const int by_lds = granules > 0 ? (lds_per_cu / 1280) / granules : occ;
   const int per_cu = std::max(1, std::min(occ > 0 ? occ : by_lds, by_lds));
   e->resident_slots = cus * per_cu;
   e->resident_for = e->lds_bytes;
@@ -723,7 +776,9 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (R.solver != PPN_SOLVER_NEWTON && R.solver != PPN_SOLVER_FDXB) return bad("solver must be NEWTON or FDXB");
   if (R.max_it <= 0) R.max_it = (R.solver == PPN_SOLVER_NEWTON) ? 10 : 25;
   if (!(R.tol > 0)) R.tol = 1e-6;
-  { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, e->newton ? 1 : 0, nullptr, &tmp); e->lds_small = ppn_carve(d, e->W, 0, nullptr, &tmp, true); }
+  { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, e->newton ? 1 : 0, nullptr, &tmp); e->lds_small = ppn_carve(d, e->W, 0, nullptr, &tmp, true);
+    e->lds_sched = ppn_carve_sched(d, e->W, nullptr, &tmp); }
+  { const char* v = getenv("PPN_SCHED_PREPASS"); if (v && v[0] == '0') e->sched_prepass = false; }
   if (e->lds_bytes > 160 * 1024) {
     free_all(e); delete e;
     return fail(nullptr, PPN_E_CAPACITY, "case needs %zu bytes of LDS per environment (limit 160 KiB)", e->lds_bytes);
@@ -737,6 +792,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   e->d_valid = dalloc<u8>(e, batch);
   e->d_perm = dalloc<int>(e, batch);
   e->d_work = dalloc<int>(e, 16);
+  e->d_progress = dalloc<int>(e, batch);
   { const char* v = getenv("PPN_PERSISTENT"); if (v && v[0] == '0') e->persistent = false; }
   { const char* v = getenv("PPN_PERSISTENT_ROUNDS"); if (v && atoi(v) > 0) e->persistent_rounds = atoi(v); }
   { const char* v = getenv("PPN_LAUNCH_ORDER"); if (v && v[0] == '0') e->order_launches = false; }
@@ -1190,6 +1246,11 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
   a.n_steps = n_steps; a.action_step_stride = per_step_actions ? mat : 0;
   a.restart_prio = e->restart_prio;
   int nblocks = e->batch;
+  // schedule pre-pass: only where node switches can change the schedule at all (busbars beyond one per substation: the four-word
+  // kernels), for the step the launch below executes first
+  if (e->sched_prepass && e->W == 4 && e->dc.NB > e->dc.nS && !simulate && e->lds_sched <= 64 * 1024) {
+    if (launch_sched<4>(e, a, e->batch)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
+  }
 #ifndef PPN_EMU
   if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first
     const int slots_ = e->persistent ? resident_slots_of(e) : 0;
@@ -1231,6 +1292,64 @@ extern "C" int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t action
     e->maybe_dead = false;
   }
   return step_launch(e, actions, actions_on_device, 0, auto_reset, n_steps, per_step_actions);
+}
+
+// ---- device-side policies -------------------------------------------------------------------------------------------------
+static int fill_policy(ppn_engine* e, KArgs* a, int32_t policy, const double* params, int32_t n_params) {
+  if (policy != PPN_POLICY_DO_NOTHING && policy != PPN_POLICY_LINE_RELIEF) return fail(e, PPN_E_INVALID, "unknown policy %d", policy);
+  if (n_params < 0 || n_params > 4 || (n_params > 0 && !params)) return fail(e, PPN_E_INVALID, "a policy takes at most 4 parameters");
+  a->policy.id = policy;
+  for (int k = 0; k < 4; ++k) a->policy.p[k] = k < n_params ? params[k] : 0.0;
+  if (policy == PPN_POLICY_LINE_RELIEF && n_params < 1) a->policy.p[0] = 1.0;      // (default threshold: the thermal limit itself)
+  return PPN_OK;
+}
+
+extern "C" int ppn_policy_actions(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, uint8_t* actions_out_device) {
+  enter(e);
+  if (!e || !actions_out_device) return PPN_E_INVALID;
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }      // the policy looks at the state
+  KArgs a = make_args(e, false);
+  { int rc = fill_policy(e, &a, policy, params, n_params); if (rc) return rc; }
+  a.policy_out = actions_out_device;
+  if (launch<K_POLICY>(e, a, e->batch)) return fail(e, PPN_E_HIP, "policy kernel launch failed: %s", dev_err());
+  return PPN_OK;
+}
+
+extern "C" int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, int32_t n_steps) {
+  enter(e);
+  if (!e || n_steps <= 0) return PPN_E_INVALID;
+  if ((long long)n_steps * e->batch > 0x7fffff00LL) return fail(e, PPN_E_INVALID, "ppn_rollout_policy: batch x n_steps exceeds the work counter");
+  if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
+  if (e->maybe_dead) {      // environments that are over right now are restarted first: every environment plays all its steps
+    int rc = ppn_process_game_over(e, nullptr);
+    if (rc) return rc;
+    e->maybe_dead = false;
+  }
+  { int rcs = settle_restarts(e); if (rcs) return rcs; }
+  KArgs a = make_args(e, false);
+  { int rc = fill_policy(e, &a, policy, params, n_params); if (rc) return rc; }
+  a.policy_out = e->d_actions;
+  a.auto_reset = 1;
+  a.restart_prio = e->restart_prio;
+  a.n_envs = e->batch; a.n_work = e->batch * n_steps;
+  a.work_counter = e->d_work; a.progress = e->d_progress;
+  int nblocks = e->batch;
+  if (dev_zero(e->d_progress, sizeof(int) * (size_t)e->batch, e->stream) || dev_zero(e->d_work, sizeof(int), e->stream))
+    return fail(e, PPN_E_HIP, "ppn_rollout_policy: clearing the progress counters failed: %s", dev_err());
+#ifndef PPN_EMU
+  {
+    // environments are handed out heaviest first within every step, as the stepped form does (the key of the LAST step before
+    // the rollout: it only shapes the start of the launch)
+    if (e->order_launches && e->batch > 1024) {
+      hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, (int*)nullptr, 0);
+      a.perm = e->d_perm;
+    }
+    const int slots_ = resident_slots_of(e);
+    nblocks = std::max(1, std::min(slots_ > 0 ? slots_ : e->batch, e->batch));
+  }
+#endif
+  if (launch<K_POLICY_ROLLOUT>(e, a, nblocks, true)) return fail(e, PPN_E_HIP, "policy rollout launch failed: %s", dev_err());
+  return PPN_OK;
 }
 
 // ---- topology-action search: K candidate actions evaluated from the current state of chosen environments --------------
@@ -1440,8 +1559,8 @@ extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int
   {   // the report of the last step is what it is; everything else shows the restarted episode
     const bool report = f == PPN_F_DONE || f == PPN_F_FLAG || f == PPN_F_ILLEGAL || f == PPN_F_REWARD || f == PPN_F_ILLEGAL_COUNTS ||
                         f == PPN_F_ACTION_SWITCHES || f == PPN_F_CASCADE_DEPTH || f == PPN_F_LINE_EVENTS || f == PPN_F_SOLVE_OUTCOME ||
-                        f == PPN_F_N_STEPS || f == PPN_F_RETURN /* counters of EXECUTED steps: a restart does not touch them */ ||
-                        (int)f == 100 /* phase counters of the profiling build */;
+                        f == PPN_F_STEP_REPORT || f == PPN_F_N_STEPS || f == PPN_F_RETURN /* counters of EXECUTED steps: a restart does not touch them */ ||
+                        (int)f == 100 /* phase counters of the profiling build */ || (int)f == 102;
     if (!report && from_simulation == 0) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   }
   FieldInfo fi; bool w;

@@ -202,6 +202,26 @@ class Engine(object):
         self._check(self._lib.ppn_rollout(self._h, C.c_void_p(int(actions_ptr)), 1, int(n_steps), 1 if per_step_actions else 0,
                                           int(auto_reset)), 'ppn_rollout')
 
+    POLICIES = {'do_nothing': 0, 'line_relief': 1}
+
+    def _policy_args(self, policy, params):
+        pid = self.POLICIES[policy] if isinstance(policy, str) else int(policy)
+        p = np.ascontiguousarray(params if params is not None else [], dtype=np.float64)
+        return pid, p, p.ctypes.data_as(C.POINTER(C.c_double)), int(p.size)
+
+    def policy_actions(self, policy, params, out_ptr):
+        """The built-in device policy's action for the CURRENT state of every environment (include/ppn.h, ppn_policy_actions),
+        written to the caller's DEVICE buffer u8 [batch x action_length] at address ``out_ptr``."""
+        pid, keep, pp, n = self._policy_args(policy, params)
+        self._check(self._lib.ppn_policy_actions(self._h, pid, pp, n, C.c_void_p(int(out_ptr))), 'ppn_policy_actions')
+
+    def rollout_policy(self, policy, params, n_steps):
+        """Closed-loop rollout of a built-in device policy (include/ppn.h, ppn_rollout_policy): ``n_steps`` rounds of
+        { policy -> action; Game.step with the fused restart } per environment in ONE launch, no environment waiting for the
+        batch between its steps; same trajectories as ``policy_actions`` + ``step_device(auto_reset=1)`` round by round."""
+        pid, keep, pp, n = self._policy_args(policy, params)
+        self._check(self._lib.ppn_rollout_policy(self._h, pid, pp, n, int(n_steps)), 'ppn_rollout_policy')
+
     def simulate(self, actions):
         a = self._actions(actions)
         self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 1, 0), 'ppn_step(simulate)')
@@ -258,6 +278,7 @@ class Engine(object):
         if bus.ndim != 3 or gen.ndim != 3 or branch.ndim != 3 or gen.shape[0] != n or branch.shape[0] != n:
             raise ValueError('runpf_arrays: bus / gen / branch must be [n x rows x columns] arrays of the same n')
         io = _lib.PpnMpcBatch()
+        io.struct_size = C.sizeof(_lib.PpnMpcBatch)
         io.n, io.bus_cols, io.gen_cols, io.branch_cols = n, bus.shape[2], gen.shape[2], branch.shape[2]
         io.bus_rows, io.gen_rows, io.branch_rows = bus.shape[1], gen.shape[1], branch.shape[1]      # (checked against the case by the library)
         bus_o, gen_o = np.empty_like(bus), np.empty_like(gen)
@@ -272,6 +293,11 @@ class Engine(object):
 
     def sync(self):
         self._check(self._lib.ppn_sync(self._h), 'ppn_sync')
+
+    def stream_ptr(self):
+        """The HIP stream the engine launches on (ppn_stream), as an integer: torch.cuda.ExternalStream(ptr) wraps it."""
+        self._lib.ppn_stream.restype = C.c_void_p
+        return int(self._lib.ppn_stream(self._h) or 0)
 
     def wait(self):
         """Blocks until the engine's stream is idle; unlike sync() it does not settle the restarts a deferred auto-reset owes."""
@@ -291,6 +317,20 @@ class Engine(object):
         out = np.empty((rows, nbytes // dt.itemsize), dtype=dt)
         self._check(self._lib.ppn_read(self._h, fid, out.ctypes.data, out.nbytes, 1, int(simulation)), 'ppn_read')
         return out[:, 0] if out.shape[1] == 1 and name not in ('OBSERVATION',) and nbytes == dt.itemsize else out
+
+    def schedule_builds_in_kernel(self):
+        """Schedules that environments had to build INSIDE a solve since the engine was created (internal field 102).  With the
+        schedule pre-pass on (four-word engines; PPN_SCHED_PREPASS=0 turns it off) that is what the pre-pass did not foresee."""
+        out = np.empty(self.batch, dtype=np.int32)
+        self._check(self._lib.ppn_read(self._h, 102, out.ctypes.data, out.nbytes, 1, 0), 'ppn_read')
+        return out
+
+    def schedule_caches(self):
+        """Raw schedule cache blobs of every environment (internal field 101: header, signature, index tables)."""
+        n = int(self._lib.ppn_field_bytes(self._h, 101))
+        out = np.empty((self.batch, n), dtype=np.uint8)
+        self._check(self._lib.ppn_read(self._h, 101, out.ctypes.data, out.nbytes, 1, 0), 'ppn_read')
+        return out
 
     def read_into_device(self, name, dev_ptr, nbytes, simulation=False):
         fid = _lib.FIELD_ID[name]

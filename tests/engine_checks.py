@@ -959,3 +959,123 @@ def check_rollout_equals_steps(lib_path, envname='default118', batch=24, n_steps
         a.close()
         b.close()
     return n_done
+
+
+def check_k1_rows_118(lib_path, max_active_buses=0):
+    """The K1-style rows recorded from the reference's RunEnv on default118 (tools/make_k1_rows.py: int-truncated ampere flows of
+    every line over 60 do-nothing steps, fast-decoupled XB, game overs + restarts inside) through the engine."""
+    import os
+    from helpers import ROOT
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_runs', 'default118_do_nothing_k1_rows.npz'))
+    kw = {'max_active_buses': max_active_buses} if max_active_buses else {}
+    eng, case, _, _ = make_engine(lib_path, 'default118', 2, conf={'solver': 'fdxb'}, **kw)
+    eng.reset(chronic_slot=np.zeros(2, dtype=np.int32), t0=np.zeros(2, dtype=np.int32))
+    acts = np.zeros((2, case.action_length), dtype=np.uint8)
+    n_done = 0
+    for t in range(int(ref['steps'])):
+        eng.step(acts, auto_reset=True)
+        assert np.array_equal(eng.read('DONE').astype(bool), np.array([ref['done'][t]] * 2)), t
+        amps = eng.read('AMPS')
+        # (int truncation amplifies a 1e-10 A difference into 1 A where a flow sits on an integer: allow that, and only that)
+        d = np.abs(amps.astype(np.int64) - ref['int_amps'][t][None, :])
+        near = np.abs(amps - np.round(amps)) < 1e-6
+        assert np.all((d == 0) | ((d == 1) & near)), (t, int(d.max()))
+        n_done += int(ref['done'][t])
+    eng.close()
+    return n_done
+
+
+def check_schedule_prepass(lib_path, envname='default118', steps=14, batch=12, solver='newton', seed=5, auto_reset=True, double_acts=False, **engine_kw):
+    """The schedule pre-pass (K_SCHED, round 5) against the build inside the step kernel: two engines on the same library, one with
+    the pre-pass (default), one with PPN_SCHED_PREPASS=0, stepped with the same random node-splitting / line-switching actions
+    (illegal ones, cooldowns, rejected actions, game overs and their restarts among them).  (a) every state and report field bit
+    for bit the same after every step -- the pre-pass is a cache warmer, it may not change a result; (b) the schedule caches bit for
+    bit the same (the four-wave build writes the tables the one-wave build writes); (c) with the pre-pass on NO environment ever
+    builds a schedule inside its solve: the pre-pass's copy of the legality rules foresees every topology the step ends up with."""
+    import os
+    case, cfg, chronics = load_env(envname, conf={'solver': solver})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)
+    os.environ['PPN_SCHED_PREPASS'] = '0'
+    try:
+        b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)
+    finally:
+        del os.environ['PPN_SCHED_PREPASS']
+    for e in (a, b):
+        e.reset()
+    na0, nb0 = a.schedule_builds_in_kernel(), b.schedule_builds_in_kernel()      # (the first solve of an engine builds the reference topology's schedule)
+    rng = np.random.default_rng(seed)
+    fields = ('VM', 'VA', 'PF', 'AMPS', 'PG', 'QG', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES',
+              'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN', 'SOFT_COUNT', 'N_SOLVES', 'N_ITERS', 'DONE', 'FLAG', 'ILLEGAL',
+              'CASCADE_DEPTH', 'SOLVE_OUTCOME', 'BUS_TYPE', 'CHRONIC_ROW', 'REWARD')
+    seen = dict(illegal=0, done=0, split=0)
+    for t in range(steps):
+        acts = random_actions(case, rng, batch, p_node=0.8, p_line=0.3)
+        if double_acts and t % 3 == 2:       # sometimes two substations (or more than the rules allow: rejected as a whole)
+            acts |= random_actions(case, rng, batch, p_node=0.9, p_line=0.5)
+        a.step(acts, auto_reset=auto_reset)
+        b.step(acts, auto_reset=auto_reset)
+        for f in fields:
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
+        seen['illegal'] += int((a.read('ILLEGAL') != 0).sum())
+        seen['done'] += int(a.read('DONE').sum())
+        seen['split'] += int(a.read('PRODS_NODES').sum() + a.read('LINES_OR_NODES').sum())
+        ca, cb = a.schedule_caches(), b.schedule_caches()
+        own = (a.read('PRODS_NODES').sum(axis=1) + a.read('LOADS_NODES').sum(axis=1) + a.read('LINES_OR_NODES').sum(axis=1)
+               + a.read('LINES_EX_NODES').sum(axis=1)) > 0      # environments that solve on a schedule of their own right now
+        assert np.array_equal(ca[own], cb[own]), t
+    na, nb = a.schedule_builds_in_kernel() - na0, b.schedule_builds_in_kernel() - nb0
+    assert nb.sum() > 0, 'the workload never needed a schedule of its own'
+    assert na.sum() == 0, 'environments built %d schedules inside their solves although the pre-pass ran (without it: %d)' % (na.sum(), nb.sum())
+    a.close(); b.close()
+    seen['builds_without_prepass'] = int(nb.sum())
+    return seen
+
+
+def check_policy_rollout_equals_stepping(lib_path, envname='default118', batch=8, n_steps=10, params=(0.9,), solver='newton', bench_limits=True,
+                                         **engine_kw):
+    """ppn_rollout_policy (closed-loop steps of a device-side policy, every environment on its own clock) against the stepped form:
+    n_steps rounds of { ppn_policy_actions; ppn_step(device actions, auto_reset = 1) } -- every state field, the report fields, the
+    executed-step counters and the accumulated return bit for bit the same.  Returns how often the policy acted."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env(envname, conf={'solver': solver})
+    kw = dict(engine_kw)
+    if bench_limits:
+        with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
+            kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)      # stepped
+    b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)      # one launch
+    slots, t0 = default_assignment(np.arange(batch) * 7, chronics)
+    for e in (a, b):
+        e.reset(chronic_slot=slots, t0=t0)
+        e.process_game_over()      # (environments that are over right after the reset: restarted before the first step on both sides, see ppn_rollout)
+    if lib_path is None:      # the HIP library: a device buffer
+        import torch
+        buf = torch.zeros((batch, case.action_length), dtype=torch.uint8, device='cuda')
+        ptr, host = buf.data_ptr(), (lambda: buf.cpu().numpy())
+        torch.cuda.synchronize()
+    else:                      # emulation build: "device" memory is host memory
+        buf = np.zeros((batch, case.action_length), dtype=np.uint8)
+        ptr, host = buf.ctypes.data, (lambda: buf)
+    acted = 0
+    for t in range(n_steps):
+        a.policy_actions('line_relief', params, ptr)
+        a.wait()
+        acts = host()
+        assert acts.sum(axis=1).max() <= 1 and not acts[:, :case.nP + case.nL + 2 * case.nl].any()      # one line switch at most
+        acted += int(acts.sum())
+        a.step_device(ptr, auto_reset=1)
+    a.sync()
+    b.rollout_policy('line_relief', params, n_steps)
+    b.sync()
+    for f in ('VM', 'VA', 'PF', 'QF', 'AMPS', 'PG', 'QG', 'LINES_STATUS', 'PRODS_NODES', 'LINES_OR_NODES', 'RECONNECTABLE', 'LINE_COOLDOWN',
+              'NODE_COOLDOWN', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES', 'N_ITERS', 'N_STEPS', 'RETURN', 'DONE', 'FLAG', 'ILLEGAL',
+              'REWARD', 'CASCADE_DEPTH', 'EPOCH', 'DEAD', 'STEP_REPORT'):
+        assert np.array_equal(a.read(f), b.read(f), equal_nan=True), f
+    assert int(a.read('N_STEPS').sum()) == batch * n_steps
+    assert not a.read('ILLEGAL').any()
+    a.close(); b.close()
+    return acted

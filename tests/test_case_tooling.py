@@ -46,3 +46,25 @@ def test_reference_grid_py_round_trip(tmp_path):
     assert np.array_equal(rows(back['branch']), rows(ref['branch']))
     assert back['baseMVA'] == ref['baseMVA']
     Case(back)
+
+
+@pytest.mark.parametrize('env', ['default14', 'default30', 'default118'])
+def test_matpower_m_file_and_reference_grid_py_are_the_same_case(env):
+    """The reference ships `reference_grid.m` (MATPOWER, what the Octave backend and a MATPOWER user would load) next to the
+    `reference_grid.py` that `Grid` loads (pypownet/grid.py:65): bus and gen arrays bit for bit identical, branch arrays identical
+    except RATE_A (column 5: 9900 in the .py, 0 = unlimited in the .m -- no part of a power flow).  The numeric anchors quoted
+    from MATPOWER / PYPOWER printouts (tests/physics_anchor.py: losses of runpf(case14 / 30 / 118)) therefore are about the very
+    arrays the engine solves.  Fixture: tools/make_m_fixtures.py (numbers parsed out of the .m files, no source text)."""
+    import json
+    d = os.path.join(ENVS, env, 'level0')
+    py = load_case_file(os.path.join(d, 'reference_grid.json'))
+    with open(os.path.join(d, 'reference_grid_m.json')) as f:
+        m = json.load(f)
+    assert float(m['baseMVA']) == float(py['baseMVA'])
+    assert np.array_equal(np.asarray(m['bus']), py['bus'])
+    assert np.array_equal(np.asarray(m['gen']), py['gen'])
+    mb, pb = np.asarray(m['branch']), py['branch']
+    assert mb.shape == pb.shape
+    cols = [c for c in range(mb.shape[1]) if c != 5]
+    assert np.array_equal(mb[:, cols], pb[:, cols])
+    assert np.array_equal(mb[:, 5], pb[:, 5]) or (np.all(mb[:, 5] == 0) and np.all(pb[:, 5] == 9900.0))      # (default30: equal)

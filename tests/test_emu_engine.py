@@ -171,3 +171,35 @@ def test_emu_with_nan_poisoned_lds(emu_lib, solver, monkeypatch):
     monkeypatch.setenv('PPN_EMU_LDS_FILL', '255')
     ec.check_auto_reset_and_cascade_118(emu_lib, steps=6, batch=4, solver=solver) if solver != 'dc' else \
         ec.check_do_nothing(emu_lib, 'default14_for_tests_beta', 'dc', steps=6, batch=2)
+
+
+def test_emu_k1_style_rows_on_ieee118(emu_lib):
+    assert ec.check_k1_rows_118(emu_lib, max_active_buses=118) >= 1
+
+
+@pytest.mark.parametrize('solver,auto_reset', [('newton', True), ('fdxb', 2), ('newton', 2)])
+def test_emu_schedule_prepass_is_a_pure_cache_warmer(emu_lib, solver, auto_reset):
+    st = ec.check_schedule_prepass(emu_lib, steps=12, batch=8, solver=solver, auto_reset=auto_reset, double_acts=True)
+    assert st['illegal'] > 0 and st['split'] > 0, st
+
+
+def test_emu_step_report_field(emu_lib):
+    from helpers import load_env
+    from harness import engine_with_library
+    case, cfg, chronics = load_env('default14_for_tests_alpha', conf={'solver': 'newton'})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    eng = engine_with_library(emu_lib, case, cfg, 8, chronics=chronics)
+    eng.reset()
+    rng = np.random.default_rng(9)
+    for t in range(20):
+        eng.step(ec.random_actions(case, rng, 8), auto_reset=2 if t % 2 else True)
+        rep = eng.read('STEP_REPORT')
+        assert np.array_equal(rep[:, 0] != 0, eng.read('DONE').astype(bool))
+        assert np.array_equal(rep[:, 1].astype(np.int32), eng.read('FLAG'))
+        np.testing.assert_allclose(rep[:, 2], eng.read('REWARD').sum(axis=1), rtol=1e-13, atol=1e-10)
+    eng.close()
+
+
+def test_emu_policy_rollout_equals_stepping(emu_lib):
+    assert ec.check_policy_rollout_equals_stepping(emu_lib, 'default118', batch=6, n_steps=14, params=(0.9,), max_active_buses=118) > 0
+    assert ec.check_policy_rollout_equals_stepping(emu_lib, 'default14_for_tests_alpha', batch=8, n_steps=30, params=(0.5,), bench_limits=False) > 0

@@ -417,7 +417,7 @@ def test_gpu_rccl_path_on_one_rank(tmp_path):
         "from helpers import ENVS\n"
         "B = 192\n"
         "kw = dict(config_overrides={'solver': 'newton'})\n"
-        "a = BatchedRunEnv(os.path.join(ENVS, 'default118'), 'level0', B, rank=0, world_size=1, device=0, **kw)\n"
+        "a = BatchedRunEnv(os.path.join(ENVS, 'default118'), 'level0', B, rank=0, world_size=1, device=0, device_exchange=True, **kw)\n"
         "b = BatchedRunEnv(os.path.join(ENVS, 'default118'), 'level0', B, rank=0, world_size=1, device=0, **kw)\n"
         "a.reset(); b.reset()\n"
         "rng = np.random.default_rng(3)\n"
@@ -450,7 +450,7 @@ def test_gpu_rccl_path_on_one_rank(tmp_path):
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['config'].get('single_controller') and d['config'].get('dist_backend') == 'nccl', d['config']
     keep = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(keep):
-        with open(os.path.join(keep, 'r04_bench_single_controller_1rank.json'), 'w') as f:
+        with open(os.path.join(keep, 'r05_bench_single_controller_1rank.json'), 'w') as f:
             json.dump(d, f, indent=1)
 
 
@@ -477,3 +477,51 @@ def test_gpu_engine_library_first_then_torch():
         "print('ok')\n") % (ROOT, os.path.join(ROOT, 'tests'))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize('nb', [118, 0])
+def test_gpu_k1_style_rows_on_ieee118(nb):
+    """tools/make_k1_rows.py: the reference's RunEnv on default118, do-nothing, int-truncated amperes of every line, 60 steps --
+    two-word (nb = 118) and four-word (every busbar may be active) fast-decoupled kernels."""
+    assert ec.check_k1_rows_118(HIP, max_active_buses=nb) >= 1
+
+
+@pytest.mark.parametrize('solver,auto_reset', [('newton', True), ('newton', 2), ('fdxb', 2)])
+def test_gpu_schedule_prepass_builds_the_same_tables(solver, auto_reset):
+    """Round 5: the schedule pre-pass (a four-wave workgroup per environment in front of the step kernel of the four-word
+    engines) vs the build by the environment's own wavefront inside its solve (PPN_SCHED_PREPASS=0): states, reports and the
+    schedule caches bit for bit the same over random node-splitting steps, and no environment builds a schedule inside its solve
+    once the pre-pass runs."""
+    st = ec.check_schedule_prepass(HIP, steps=30, batch=96, solver=solver, auto_reset=auto_reset, double_acts=True)
+    assert st['illegal'] > 0 and st['split'] > 0 and st['done'] > 0, st
+
+
+def test_gpu_step_report_field_mirrors_done_flag_reward():
+    """PPN_F_STEP_REPORT (libppn 0.2): one [3] row per environment = (done, flag, sum of the reward components) of the last step."""
+    from helpers import load_env
+    from harness import engine_with_library
+    case, cfg, chronics = load_env('default118', conf={'solver': 'newton'})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    eng = engine_with_library(HIP, case, cfg, 64, chronics=chronics)
+    eng.reset()
+    rng = np.random.default_rng(9)
+    seen = 0
+    for t in range(25):
+        eng.step(ec.random_actions(case, rng, 64), auto_reset=2 if t % 2 else True)
+        rep = eng.read('STEP_REPORT')
+        assert np.array_equal(rep[:, 0] != 0, eng.read('DONE').astype(bool))
+        assert np.array_equal(rep[:, 1].astype(np.int32), eng.read('FLAG'))
+        np.testing.assert_allclose(rep[:, 2], eng.read('REWARD').sum(axis=1), rtol=1e-13, atol=1e-10)
+        seen += int(eng.read('DONE').sum())
+    assert seen > 0
+    eng.close()
+
+
+@pytest.mark.parametrize('env,batch,steps,thr,kw', [('default118', 2048, 12, 0.9, dict(max_active_buses=118)),
+                                                   ('default118', 96, 10, 0.8, dict()),
+                                                   ('default14', 512, 30, 0.5, dict())])
+def test_gpu_policy_rollout_equals_stepping(env, batch, steps, thr, kw):
+    """Round 5: closed-loop steps of a device-side policy with every environment on its own clock
+    (ppn_rollout_policy: work items (step, environment) handed to whichever workgroup is free) -- trajectories bit for bit those of
+    synchronous stepping with the same policy."""
+    assert ec.check_policy_rollout_equals_stepping(HIP, env, batch=batch, n_steps=steps, params=(thr,), bench_limits=(env == 'default118'), **kw) > 0

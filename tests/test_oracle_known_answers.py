@@ -223,3 +223,21 @@ def test_k9_chronic_passthrough_and_slack():
         assert np.array_equal(obs['reactive_loads'], ch.loads_q[row].astype(np.float64))
         assert np.array_equal(obs['active_productions'][1:], ch.prods_p[row][1:].astype(np.float64))
         assert abs(obs['active_productions'][0] - ch.prods_p[row][0]) < 1.0   # slack closes the losses (MW)
+
+
+def test_k1_style_rows_on_ieee118_recorded_from_the_reference():
+    """K1's kind of known answer on IEEE-118 (tools/make_k1_rows.py): int-truncated ampere flows of all 186 lines over 60
+    do-nothing steps of the reference's own RunEnv on default118 (fast-decoupled XB, shipped limits, 8 game overs and their
+    restarts inside).  The recording ran on the numpy restatement of PYPOWER; `python tools/make_k1_rows.py --check` repeats it
+    with the real PYPOWER where that is installed.  Here: the oracle game reproduces every row."""
+    import os
+    from helpers import load_env, ROOT
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_runs', 'default118_do_nothing_k1_rows.npz'))
+    game = oracle_game('default118')
+    case, _, _ = load_env('default118')
+    for t in range(int(ref['steps'])):
+        done = game.step(do_nothing(case))[3]
+        assert bool(done) == bool(ref['done'][t]), t
+        if done:
+            game.process_game_over()
+        assert np.array_equal(game.extract_flows_a().astype(np.int64), ref['int_amps'][t]), t

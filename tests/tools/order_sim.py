@@ -3,6 +3,8 @@ Every environment's body time of step t + 1 is recorded next to what was known a
 build leaves in its counters: largest line loading, the loading of in-service lines that the NEXT chronic row takes out, ...).
 A greedy list schedule over the resident slots (256 CUs x 7) replays the launch under each key: environments are handed out
 in key order, a slot takes the next one when it is free.  'oracle' sorts by the true body time (longest first).
+The feature slots (23-28) are only written by a library built with -DPPN_PROF -DPPN_PROF_ORDER (a plain -DPPN_PROF build keeps
+schedule_build's sub-phase counters there): PPN_PROF_FLAGS=-DPPN_PROF_ORDER PPN_REBUILD=1 python tools/profile_phases.py first.
 Usage: python tests/tools/order_sim.py [steps]"""
 import heapq, os, sys, numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))

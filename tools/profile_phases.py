@@ -71,7 +71,6 @@ def main():
         unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
         per = tot[k] / {'iteration': nit, 'env-step': float(B * steps), 'solve': nsolve}[unit]
         print('%-28s total %.3e cyc  %8.0f cyc per %s' % (name, tot[k], per, unit))
-    print('cascade re-solves that took the short way in: %d of %d solves' % (tot[30], nsolve))
     if conf['solver'] == 'fdxb':
         for k, name in enumerate(("B', B'' assembly", "factorisation of B', B'' (+ tail inverses, scaled L)", 'V = |V| e^{ja} (+ clears)',
                                   'mismatch over the Ybus entries', 'norm, right-hand side', 'forward substitution + tail', 'backward substitution + update')):
