@@ -48,6 +48,7 @@ static inline int ppn_emu_lane_of(int pos) {
 #define WSYNC() ((void)0)
 #define WSYNC_G() ((void)0)
 #define PPN_SCHED_FENCE() ((void)0)
+#define PPN_WAVE_FULL(prof_, id) ((void)0)
 // per-lane variables that live across LANE_LOOP regions (registers on the GPU)
 #define PPN_OPAQUE_S(x) (x)
 #define PPN_OPAQUE_V(x) (x)
@@ -95,6 +96,36 @@ __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" :
 #endif
 #define WSYNC_G() __syncthreads()
 #define PPN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)      // the instruction scheduler moves nothing across this point
+// PPN_WAVE_FULL(): a full compiler + EXEC fence at the wave-uniform points of a kernel (round 5).
+// One wavefront plays one environment and every decision between phases is the same in all 64 lanes.  At such a point -- never
+// inside a LANE_LOOP or under a per-lane condition -- the statement (a) sets EXEC to all ones and (b), being an `asm volatile` with a
+// memory clobber, keeps the compiler from moving or merging memory accesses across it.
+// Why it exists: the closed-loop rollout kernel (K_POLICY_ROLLOUT, ppn_kernels.inc) FAULTS on the GPU as first written -- a work
+// loop around policy_action + body_step -- and runs correctly with this statement at the head of the loop (tools/ubench/
+// README_gpu_only_failures.md: reproducer, -DPPN_WAVE_FULL_OFF builds the failing kernel).  What round 5 established about this class
+// of GPU-only failures (also: the round-2 tree with the line-end tables inside the matrix region, rebuilt in variants):
+//   * they do NOT depend on waiting: s_waitcnt lgkmcnt(0), or vmcnt(0) lgkmcnt(0), at every phase boundary changes nothing;
+//   * they DO depend on the optimisation level: the round-2 tree passes at -O1 and -O2 and fails at -O3;
+//   * lanes are NOT found parked: -DPPN_EXEC_CHECK records EXEC != all-ones at these points -- zero events -- and setting EXEC at
+//     the round-2 tree's loop heads does not cure it.  For the rollout kernel the cure therefore is (b): code motion across the
+//     loop head, not a lost EXEC mask;
+//   * the lane-serial emulation cannot see them in any lane order (tests/test_emu_lane_order.py): not an ordering assumption of
+//     the kernels' own.
+// It stays at the loop heads as a hardening: one scalar instruction where the phase boundary is a compiler fence anyway.
+// -DPPN_EXEC_CHECK additionally records (bit `id` of the environment's prof[31], count in prof[30]) lanes found missing there.
+#if defined(PPN_WAVE_FULL_OFF)      // (the kernels as they were written until round 5: for the reproducer only)
+#define PPN_WAVE_FULL(prof_, id) ((void)0)
+#elif defined(PPN_WAVE_FULL_BARRIER_ONLY)      // (reproducer: the compiler fence without the EXEC write)
+#define PPN_WAVE_FULL(prof_, id) __asm__ volatile("" ::: "memory")
+#elif defined(PPN_WAVE_FULL_EXEC_ONLY)         // (reproducer: the EXEC write without the compiler fence)
+#define PPN_WAVE_FULL(prof_, id) __asm__ volatile("s_mov_b64 exec, -1")
+#elif defined(PPN_EXEC_CHECK)      // (= 2: inside the step body -- ids 4 and up -- lanes found parked are recorded but NOT switched on: where does it start?)
+#define PPN_WAVE_FULL(prof_, id) do { const u64 ex_ = __builtin_amdgcn_read_exec(); \
+    if (PPN_EXEC_CHECK != 2 || (id) < 4) __asm__ volatile("s_mov_b64 exec, -1" ::: "memory"); \
+    if (ex_ != ~0ull && (prof_) != nullptr && (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(ex_)) { (prof_)[31] |= 1ll << (id); (prof_)[30] += 1; } } while (0)
+#else
+#define PPN_WAVE_FULL(prof_, id) __asm__ volatile("s_mov_b64 exec, -1" ::: "memory")
+#endif
 #define LANE_VAR(type, name) type name
 #define LANE_ARR(type, name, n) type name[n]
 #define LV(name) name

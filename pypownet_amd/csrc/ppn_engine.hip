@@ -84,7 +84,12 @@ struct ppn_engine {
   size_t lds_bytes = 0;
   size_t lds_small = 0;       // compact carve of the kernels without a solve (K_VALID, K_OBS)
   size_t lds_sched = 0;       // carve of the schedule pre-pass (ppn_carve_sched)
-  bool sched_prepass = true;  // PPN_SCHED_PREPASS=0: schedules are only ever built inside the step kernel, as until round 4
+  // schedule pre-pass (body_sched): PPN_SCHED_PREPASS = 0 never (schedules are built inside the step kernel, as until round 4),
+  // 64 / 256 always, with that many threads per environment; default (1): one-wave workgroups when the batch is at least
+  // PPN_SCHED_PREPASS_ROUNDS (2) times what the step kernel holds at once -- the throughput regime, where a build inside the step
+  // kernel occupies a solver slot (40 KB of LDS, 1 wave per SIMD) for 67-90 k cycles and a build in the pre-pass a 23 KB one; below
+  // that a launch lasts as long as its longest environment either way and the pre-pass would only add its own launch to it
+  int sched_prepass = 1, sched_threads = 64, sched_rounds = 2;
   // Q plane of the Newton storage (Smem): sized from the chronics unless rules.lu_capacity fixes the storage
   bool auto_qcap = true;
   std::vector<int> rowlen_sub, sub_gen_;   // filled-pattern row length of every substation's busbar, production of a substation (-1: none)
@@ -151,6 +156,14 @@ static T* dalloc(ppn_engine* e, size_t n) {
 
 #include "ppn_kernels.inc"
 
+// dispatch on the bitset width of the engine's kernels (-DPPN_ONLY_W1, developer builds for compiler bisection: only the one-word
+// kernels are instantiated)
+#ifdef PPN_ONLY_W1
+#define PPN_BY_W(w_, x1, x2, x4) (x1)
+#else
+#define PPN_BY_W(w_, x1, x2, x4) ((w_) == 1 ? (x1) : ((w_) == 2 ? (x2) : (x4)))
+#endif
+
 template <int W, int KIND, int NT>
 static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
 #ifdef PPN_EMU
@@ -215,8 +228,13 @@ static int launch_sched(ppn_engine* e, const KArgs& a, int nblocks) {
   }
   return 0;
 #else
-  if (e->newton) hipLaunchKernelGGL((ppn_sched_kernel<W, 1>), dim3(nblocks), dim3(PPN_SCHED_THREADS), e->lds_sched, e->stream, a);
-  else hipLaunchKernelGGL((ppn_sched_kernel<W, 0>), dim3(nblocks), dim3(PPN_SCHED_THREADS), e->lds_sched, e->stream, a);
+  if (e->sched_threads == 256) {
+    if (e->newton) hipLaunchKernelGGL((ppn_sched_kernel<W, 1, 256>), dim3(nblocks), dim3(256), e->lds_sched, e->stream, a);
+    else hipLaunchKernelGGL((ppn_sched_kernel<W, 0, 256>), dim3(nblocks), dim3(256), e->lds_sched, e->stream, a);
+  } else {
+    if (e->newton) hipLaunchKernelGGL((ppn_sched_kernel<W, 1, 64>), dim3(nblocks), dim3(64), e->lds_sched, e->stream, a);
+    else hipLaunchKernelGGL((ppn_sched_kernel<W, 0, 64>), dim3(nblocks), dim3(64), e->lds_sched, e->stream, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
 }
@@ -231,11 +249,15 @@ static int launch_nt(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
 }
 template <int KIND>
 static int launch(ppn_engine* e, const KArgs& a, int nblocks, bool timed = false) {
+#ifdef PPN_ONLY_W1      // (developer builds for compiler bisection, tools/ubench/: the one-word kernels only)
+  return e->W == 1 ? launch_nt<1, KIND>(e, a, nblocks, timed) : -1;
+#else
   switch (e->W) {
     case 1: return launch_nt<1, KIND>(e, a, nblocks, timed);
     case 2: return launch_nt<2, KIND>(e, a, nblocks, timed);
     default: return launch_nt<4, KIND>(e, a, nblocks, timed);
   }
+#endif
 }
 
 #ifndef PPN_EMU
@@ -470,7 +492,7 @@ static int resident_slots_of(ppn_engine* e) {
   if (e->resident_for == e->lds_bytes && e->resident_slots > 0) return e->resident_slots;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) return 0;
-  const int occ = e->W == 1 ? step_kernel_occupancy<1>(e, true) : (e->W == 2 ? step_kernel_occupancy<2>(e, true) : step_kernel_occupancy<4>(e, true));
+  const int occ = PPN_BY_W(e->W, step_kernel_occupancy<1>(e, true), step_kernel_occupancy<2>(e, true), step_kernel_occupancy<4>(e, true));
   const int granules = (int)((e->lds_bytes + 1279) / 1280);
   int lds_per_cu = 0;      // bytes of LDS a CU hands out, in granules of 1280 bytes (gfx950: 160 KiB = 128 granules)
   if (hipDeviceGetAttribute(&lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, e->device) != hipSuccess || lds_per_cu <= 0) lds_per_cu = 160 * 1024;
@@ -490,7 +512,7 @@ extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
     return 1;
 #else
     enter(e);
-    return e->W == 1 ? step_kernel_occupancy<1>(e) : (e->W == 2 ? step_kernel_occupancy<2>(e) : step_kernel_occupancy<4>(e));
+    return PPN_BY_W(e->W, step_kernel_occupancy<1>(e), step_kernel_occupancy<2>(e), step_kernel_occupancy<4>(e));
 #endif
   }
   switch (which) {
@@ -778,7 +800,8 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (!(R.tol > 0)) R.tol = 1e-6;
   { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, e->newton ? 1 : 0, nullptr, &tmp); e->lds_small = ppn_carve(d, e->W, 0, nullptr, &tmp, true);
     e->lds_sched = ppn_carve_sched(d, e->W, nullptr, &tmp); }
-  { const char* v = getenv("PPN_SCHED_PREPASS"); if (v && v[0] == '0') e->sched_prepass = false; }
+  { const char* v = getenv("PPN_SCHED_PREPASS"); if (v) { const int k = atoi(v); e->sched_prepass = (k == 0) ? 0 : (k == 64 || k == 256 ? 2 : 1); if (k == 256) e->sched_threads = 256; } }
+  { const char* v = getenv("PPN_SCHED_PREPASS_ROUNDS"); if (v && atoi(v) > 0) e->sched_rounds = atoi(v); }
   if (e->lds_bytes > 160 * 1024) {
     free_all(e); delete e;
     return fail(nullptr, PPN_E_CAPACITY, "case needs %zu bytes of LDS per environment (limit 160 KiB)", e->lds_bytes);
@@ -803,8 +826,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   if (e->mem_failed) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation or upload failed: %s", dev_err()); }
 #ifndef PPN_EMU
   int rc_attr = 0;
-  switch (e->W) { case 1: rc_attr = set_lds_attr<1>(e->lds_bytes); break; case 2: rc_attr = set_lds_attr<2>(e->lds_bytes); break;
-                  default: rc_attr = set_lds_attr<4>(e->lds_bytes); }
+  rc_attr = PPN_BY_W(e->W, set_lds_attr<1>(e->lds_bytes), set_lds_attr<2>(e->lds_bytes), set_lds_attr<4>(e->lds_bytes));
   if (rc_attr) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, dev_err()); }
   if (hipStreamSynchronize(e->stream) != hipSuccess) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "upload failed: %s", dev_err()); }
 #endif
@@ -876,8 +898,7 @@ static int size_q_plane(ppn_engine* e) {
   { const char* v = getenv("PPN_LDS_PAD"); if (v) e->lds_bytes += (size_t)atoi(v); }      // (occupancy experiments: fewer environments per CU)
 #ifndef PPN_EMU
   int rc_attr = 0;
-  switch (e->W) { case 1: rc_attr = set_lds_attr<1>(e->lds_bytes); break; case 2: rc_attr = set_lds_attr<2>(e->lds_bytes); break;
-                  default: rc_attr = set_lds_attr<4>(e->lds_bytes); }
+  rc_attr = PPN_BY_W(e->W, set_lds_attr<1>(e->lds_bytes), set_lds_attr<2>(e->lds_bytes), set_lds_attr<4>(e->lds_bytes));
   if (rc_attr) return fail(e, PPN_E_HIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, dev_err());
 #endif
   return PPN_OK;
@@ -1249,7 +1270,15 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
   // schedule pre-pass: only where node switches can change the schedule at all (busbars beyond one per substation: the four-word
   // kernels), for the step the launch below executes first
   if (e->sched_prepass && e->W == 4 && e->dc.NB > e->dc.nS && !simulate && e->lds_sched <= 64 * 1024) {
-    if (launch_sched<4>(e, a, e->batch)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
+    bool run = e->sched_prepass == 2;
+#ifndef PPN_EMU
+    if (!run) { const int slots_ = resident_slots_of(e); run = slots_ > 0 && (long)e->sched_rounds * slots_ <= (long)e->batch; }
+#else
+    run = true;      // (the emulation build always runs it: the tests exercise the code)
+#endif
+#ifndef PPN_ONLY_W1
+    if (run && launch_sched<4>(e, a, e->batch)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
+#endif
   }
 #ifndef PPN_EMU
   if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first

@@ -966,7 +966,7 @@ def check_k1_rows_118(lib_path, max_active_buses=0):
     every line over 60 do-nothing steps, fast-decoupled XB, game overs + restarts inside) through the engine."""
     import os
     from helpers import ROOT
-    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_runs', 'default118_do_nothing_k1_rows.npz'))
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'k1_rows', 'default118_do_nothing_k1_rows.npz'))
     kw = {'max_active_buses': max_active_buses} if max_active_buses else {}
     eng, case, _, _ = make_engine(lib_path, 'default118', 2, conf={'solver': 'fdxb'}, **kw)
     eng.reset(chronic_slot=np.zeros(2, dtype=np.int32), t0=np.zeros(2, dtype=np.int32))
@@ -985,7 +985,8 @@ def check_k1_rows_118(lib_path, max_active_buses=0):
     return n_done
 
 
-def check_schedule_prepass(lib_path, envname='default118', steps=14, batch=12, solver='newton', seed=5, auto_reset=True, double_acts=False, **engine_kw):
+def check_schedule_prepass(lib_path, envname='default118', steps=14, batch=12, solver='newton', seed=5, auto_reset=True, double_acts=False, threads=64,
+                           **engine_kw):
     """The schedule pre-pass (K_SCHED, round 5) against the build inside the step kernel: two engines on the same library, one with
     the pre-pass (default), one with PPN_SCHED_PREPASS=0, stepped with the same random node-splitting / line-switching actions
     (illegal ones, cooldowns, rejected actions, game overs and their restarts among them).  (a) every state and report field bit
@@ -995,9 +996,10 @@ def check_schedule_prepass(lib_path, envname='default118', steps=14, batch=12, s
     import os
     case, cfg, chronics = load_env(envname, conf={'solver': solver})
     case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
-    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)
-    os.environ['PPN_SCHED_PREPASS'] = '0'
+    os.environ['PPN_SCHED_PREPASS'] = str(threads)      # (forced on: by default the engine only runs it in the throughput regime)
     try:
+        a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)
+        os.environ['PPN_SCHED_PREPASS'] = '0'
         b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)
     finally:
         del os.environ['PPN_SCHED_PREPASS']

@@ -486,13 +486,13 @@ def test_gpu_k1_style_rows_on_ieee118(nb):
     assert ec.check_k1_rows_118(HIP, max_active_buses=nb) >= 1
 
 
-@pytest.mark.parametrize('solver,auto_reset', [('newton', True), ('newton', 2), ('fdxb', 2)])
-def test_gpu_schedule_prepass_builds_the_same_tables(solver, auto_reset):
+@pytest.mark.parametrize('solver,auto_reset,threads', [('newton', True, 256), ('newton', 2, 64), ('fdxb', 2, 256), ('fdxb', True, 64)])
+def test_gpu_schedule_prepass_builds_the_same_tables(solver, auto_reset, threads):
     """Round 5: the schedule pre-pass (a four-wave workgroup per environment in front of the step kernel of the four-word
     engines) vs the build by the environment's own wavefront inside its solve (PPN_SCHED_PREPASS=0): states, reports and the
     schedule caches bit for bit the same over random node-splitting steps, and no environment builds a schedule inside its solve
     once the pre-pass runs."""
-    st = ec.check_schedule_prepass(HIP, steps=30, batch=96, solver=solver, auto_reset=auto_reset, double_acts=True)
+    st = ec.check_schedule_prepass(HIP, steps=30, batch=96, solver=solver, auto_reset=auto_reset, double_acts=True, threads=threads)
     assert st['illegal'] > 0 and st['split'] > 0 and st['done'] > 0, st
 
 

@@ -232,7 +232,7 @@ def test_k1_style_rows_on_ieee118_recorded_from_the_reference():
     with the real PYPOWER where that is installed.  Here: the oracle game reproduces every row."""
     import os
     from helpers import load_env, ROOT
-    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_runs', 'default118_do_nothing_k1_rows.npz'))
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'k1_rows', 'default118_do_nothing_k1_rows.npz'))
     game = oracle_game('default118')
     case, _, _ = load_env('default118')
     for t in range(int(ref['steps'])):

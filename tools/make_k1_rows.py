@@ -5,7 +5,7 @@ The reference's own tests pin its numeric layer with ONE series: the int-truncat
 steps on IEEE-14 (`tests/test_core.py:919`).  This tool records the same kind of rows on default118: the
 reference's unmodified RunEnv (imported in place, tools/make_reference_fixtures.py's stand-ins for gym and pypower.api), the
 do-nothing agent, the reference's solver (fast-decoupled XB), shipped thermal limits, `int(ampere_flows)` of all 186 lines after
-every step -> tests/golden/reference_runs/default118_do_nothing_k1_rows.npz (data only).
+every step -> tests/golden/k1_rows/default118_do_nothing_k1_rows.npz (data only).
 
     python tools/make_k1_rows.py              # record (pypower.api = oracle/pf_np.py, as every recording here)
     python tools/make_k1_rows.py --check      # a container WITH PYPOWER 5.1.4 and gym installed: drive the REAL reference stack and
@@ -22,7 +22,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import make_reference_fixtures as mrf      # noqa: E402
 
-OUT = os.path.join(mrf.OUT, 'default118_do_nothing_k1_rows.npz')
+OUT = os.path.join(mrf.ROOT, 'tests', 'golden', 'k1_rows', 'default118_do_nothing_k1_rows.npz')
 STEPS = 60
 
 
