@@ -373,7 +373,9 @@ int32_t ppn_dim(const ppn_engine* e, int32_t which);   /* 0 nS, 1 nP, 2 nL, 3 nl
                                                           12-14 capacities of the elimination schedule (filled 2x2
                                                           block entries, Schur pair records, triple records), 15 Q-plane
                                                           capacity of the Newton storage, 16 environments resident per CU
-                                                          (hipOccupancyMaxActiveBlocksPerMultiprocessor of the step kernel) */
+                                                          (hipOccupancyMaxActiveBlocksPerMultiprocessor of the step kernel),
+                                                          17 / 18 two-capacity stepping: pattern capacity and LDS bytes of the
+                                                          small-storage launch (0: off -- see rules.lu_capacity) */
 const char* ppn_version(void);
 
 #ifdef __cplusplus

@@ -296,6 +296,8 @@ struct DevState {
   int *rec, *lcd, *ncd, *soft;     // counters
   u8 *done, *dead, *succ, *btype;   // done: reported by the last step; dead: must be reset before stepping
   int *flag, *ill, *depth, *nsolve, *niter, *slot, *row, *nlc, *npc, *epoch;
+  u8* big;                         // two-capacity stepping (ppn_engine.hip): 1 = the topology this environment's next step solves on needs the large
+                                   // matrix storage (written by the schedule pre-pass before every step)
   int* nbuild;                     // schedules this environment's own wavefront had to build inside a solve since ppn_reset (internal field 102: with the
                                    // schedule pre-pass on, that is what the pre-pass did not foresee)
   int* nstep;                      // Game.step calls this environment has executed since ppn_reset (PPN_F_N_STEPS)

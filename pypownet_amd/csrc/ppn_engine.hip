@@ -90,6 +90,19 @@ struct ppn_engine {
   // kernel occupies a solver slot (40 KB of LDS, 1 wave per SIMD) for 67-90 k cycles and a build in the pre-pass a 23 KB one; below
   // that a launch lasts as long as its longest environment either way and the pre-pass would only add its own launch to it
   int sched_prepass = 1, sched_threads = 64, sched_rounds = 2;
+  // Two-capacity stepping (round 5) of the engines whose busbars may split, when the caller left the matrix capacity to the
+  // engine (rules.lu_capacity = 0): the capacity that is safe for every topology (pattern 2.15 x the base one, full Q plane: 55 KB of
+  // LDS, two environments per CU) is needed by hardly any (the largest pattern over 10^6 random topologies is 1.39 x).  ppn_step
+  // therefore launches the step kernel twice: carved for a SMALL storage -- the largest P = Q capacity that still lets four
+  // environments share a CU (1.48 x at IEEE-118) -- for the environments whose schedule fits it, then carved for the large one for
+  // the rest (usually none: the workgroups of that launch return at once).  Which class an environment is in is decided BEFORE its
+  // step touches anything, by the schedule pre-pass, from the pattern size of the schedule the step will solve on (the small Q
+  // plane is as large as the small P plane, so nothing else can overflow).  PPN_TWO_CAP=0 turns it off.
+  bool two_cap = false, two_cap_allowed = true;
+  int two_cap_forced = 0;         // (tests, PPN_TWO_CAP_ECAP: a small storage so small that some environments need the large one)
+  int ecap_small = 0;             // pattern capacity (P plane = Q plane) of the small storage
+  size_t lds_small_cap = 0;       // LDS per environment of the small-storage launch
+  size_t lds_override = 0;        // (launch_w: dynamic LDS of the launch in flight when it is not lds_bytes)
   // Q plane of the Newton storage (Smem): sized from the chronics unless rules.lu_capacity fixes the storage
   bool auto_qcap = true;
   std::vector<int> rowlen_sub, sub_gen_;   // filled-pattern row length of every substation's busbar, production of a substation (-1: none)
@@ -184,7 +197,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   }
   for (int env = 0; env < nblocks; ++env) {
     memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
-    if (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_STEP_PERSIST) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0); }
+    if (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_STEP_PERSIST) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0, a.cap_class); }
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
@@ -206,7 +219,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     (void)hipEventRecord(e0, e->stream);
   }
-  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), (KIND == K_VALID || KIND == K_OBS || KIND == K_POLICY) ? e->lds_small : e->lds_bytes, e->stream, a);
+  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), (KIND == K_VALID || KIND == K_OBS || KIND == K_POLICY) ? e->lds_small : (e->lds_override ? e->lds_override : e->lds_bytes), e->stream, a);
   if (timed) { (void)hipEventRecord(e1, e->stream); e->launches++; }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
@@ -223,8 +236,8 @@ static int launch_sched(ppn_engine* e, const KArgs& a, int nblocks) {
   ppn_carve_sched(a.d, W, base, &S);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, e->lds_sched);
-    if (e->newton) body_sched<W, PPN_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0);
-    else body_sched<W, PPN_FD_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0);
+    if (e->newton) body_sched<W, PPN_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0, a.ecap_small);
+    else body_sched<W, PPN_FD_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0, a.ecap_small);
   }
   return 0;
 #else
@@ -386,7 +399,7 @@ static int alloc_state(ppn_engine* e, DevState* s, size_t B) {
   s->flag = dalloc<int>(e, B); s->ill = dalloc<int>(e, B); s->depth = dalloc<int>(e, B);
   s->nsolve = dalloc<int>(e, B); s->niter = dalloc<int>(e, B); s->slot = dalloc<int>(e, B);
   s->row = dalloc<int>(e, B); s->nlc = dalloc<int>(e, B); s->npc = dalloc<int>(e, B); s->epoch = dalloc<int>(e, B);
-  s->nstep = dalloc<int>(e, B); s->nbuild = dalloc<int>(e, B);
+  s->nstep = dalloc<int>(e, B); s->nbuild = dalloc<int>(e, B); s->big = dalloc<u8>(e, B);
   s->prow = dalloc<int>(e, B); s->lev = dalloc<u8>(e, B * d.nl); s->src = dalloc<int>(e, B); s->draws = dalloc<unsigned>(e, B);
   s->prof = dalloc<long long>(e, B * 32);
   s->prio = dalloc<float>(e, B);
@@ -403,6 +416,9 @@ static bool field_info(const ppn_engine* e, ppn_field f, FieldInfo* fi, bool* wr
   const DevCase& d = e->dc;
   if ((int)f == 100) {   /* phase cycle counters of -DPPN_PROF builds (tools/profile_phases.py) */
     fi->elem = sizeof(long long); fi->n = 32; fi->off = offsetof(DevState, prof); *writable = true; return true;
+  }
+  if ((int)f == 103) {   /* two-capacity stepping: capacity class the schedule pre-pass gave every environment for its last step */
+    fi->elem = 1; fi->n = 1; fi->off = offsetof(DevState, big); *writable = false; return true;
   }
   if ((int)f == 102) {   /* schedules built INSIDE a solve since the engine was created (what the schedule pre-pass did not foresee) */
     fi->elem = sizeof(int); fi->n = 1; fi->off = offsetof(DevState, nbuild); *writable = false; return true;
@@ -470,17 +486,18 @@ extern "C" size_t ppn_field_bytes(const ppn_engine* e, ppn_field f) {
 
 #ifndef PPN_EMU
 template <int W>
-static int step_kernel_occupancy(const ppn_engine* e, bool persistent_form = false) {
+static int step_kernel_occupancy(const ppn_engine* e, bool persistent_form = false, size_t lds = 0) {
   int n = 0;
   hipError_t rc;
+  if (!lds) lds = e->lds_bytes;
   // (the persistent form is a kernel symbol of its own -- a loop around the body, its own register allocation: the grid of that
   //  launch is sized from ITS occupancy)
   if (persistent_form)
-    rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP_PERSIST, 1>, 64, e->lds_bytes)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP_PERSIST, 0>, 64, e->lds_bytes);
+    rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP_PERSIST, 1>, 64, lds)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP_PERSIST, 0>, 64, lds);
   else
-    rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 1>, 64, e->lds_bytes)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 0>, 64, e->lds_bytes);
+    rc = e->newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 1>, 64, lds)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppn_kernel<W, K_STEP, 0>, 64, lds);
   return rc == hipSuccess ? n : -1;
 }
 #endif
@@ -488,18 +505,19 @@ static int step_kernel_occupancy(const ppn_engine* e, bool persistent_form = fal
 #ifndef PPN_EMU
 // workgroups of the step kernel resident at once: CUs x min(what the runtime computes, what the 1280-byte LDS granules allow --
 // the runtime's figure was one too high for a 23 248-byte build)
-static int resident_slots_of(ppn_engine* e) {
-  if (e->resident_for == e->lds_bytes && e->resident_slots > 0) return e->resident_slots;
+static int resident_slots_of(ppn_engine* e, size_t lds = 0) {
+  if (!lds) lds = e->lds_bytes;
+  if (e->resident_for == lds && e->resident_slots > 0) return e->resident_slots;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) return 0;
-  const int occ = PPN_BY_W(e->W, step_kernel_occupancy<1>(e, true), step_kernel_occupancy<2>(e, true), step_kernel_occupancy<4>(e, true));
-  const int granules = (int)((e->lds_bytes + 1279) / 1280);
+  const int occ = PPN_BY_W(e->W, step_kernel_occupancy<1>(e, true, lds), step_kernel_occupancy<2>(e, true, lds), step_kernel_occupancy<4>(e, true, lds));
+  const int granules = (int)((lds + 1279) / 1280);
   int lds_per_cu = 0;      // bytes of LDS a CU hands out, in granules of 1280 bytes (gfx950: 160 KiB = 128 granules)
   if (hipDeviceGetAttribute(&lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, e->device) != hipSuccess || lds_per_cu <= 0) lds_per_cu = 160 * 1024;
   const int by_lds = granules > 0 ? (lds_per_cu / 1280) / granules : occ;
   const int per_cu = std::max(1, std::min(occ > 0 ? occ : by_lds, by_lds));
   e->resident_slots = cus * per_cu;
-  e->resident_for = e->lds_bytes;
+  e->resident_for = lds;
   return e->resident_slots;
 }
 #endif
@@ -520,6 +538,7 @@ extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
     case 4: return d.alen; case 5: return d.obslen; case 6: return e->batch; case 7: return (int32_t)e->lds_bytes;
     case 8: return d.NB; case 9: return d.LUCAP; case 10: return (int32_t)e->chronics.size(); case 11: return e->base_fill;
     case 12: return d.ECAP; case 13: return d.MCAP; case 14: return d.TCAP; case 15: return d.QCAP;
+    case 17: return e->two_cap ? e->ecap_small : 0; case 18: return e->two_cap ? (int32_t)e->lds_small_cap : 0;
     default: return -1;
   }
 }
@@ -801,6 +820,8 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   { Smem tmp; e->lds_bytes = ppn_carve(d, e->W, e->newton ? 1 : 0, nullptr, &tmp); e->lds_small = ppn_carve(d, e->W, 0, nullptr, &tmp, true);
     e->lds_sched = ppn_carve_sched(d, e->W, nullptr, &tmp); }
   { const char* v = getenv("PPN_SCHED_PREPASS"); if (v) { const int k = atoi(v); e->sched_prepass = (k == 0) ? 0 : (k == 64 || k == 256 ? 2 : 1); if (k == 256) e->sched_threads = 256; } }
+  { const char* v = getenv("PPN_TWO_CAP"); if (v && v[0] == '0') e->two_cap_allowed = false; }
+  { const char* v = getenv("PPN_TWO_CAP_ECAP"); if (v) e->two_cap_forced = atoi(v); }
   { const char* v = getenv("PPN_SCHED_PREPASS_ROUNDS"); if (v && atoi(v) > 0) e->sched_rounds = atoi(v); }
   if (e->lds_bytes > 160 * 1024) {
     free_all(e); delete e;
@@ -867,9 +888,10 @@ static int index_of(const std::vector<int>& v, int x) { for (size_t i = 0; i < v
 // that lose all their lines only lower it); with spare busbars the same fraction of the filled pattern plus a margin is
 // reserved.  A solve that needs more (state written through ppn_write, an unusual split) reports PPN_FLAG_ENGINE_CAPACITY
 // like any other capacity; rules.lu_capacity reserves the full planes.
+static void setup_two_cap(ppn_engine* e);
 static int size_q_plane(ppn_engine* e) {
   DevCase& d = e->dc;
-  if (!e->newton || !e->auto_qcap) return PPN_OK;
+  if (!e->newton || !e->auto_qcap) { setup_two_cap(e); return PPN_OK; }
   const int nS = d.nS, nP = d.nP;
   std::vector<int> gen_sub(nP);
   for (int s_ = 0; s_ < nS; ++s_) if (e->sub_gen_[s_] >= 0) gen_sub[e->sub_gen_[s_]] = s_;
@@ -901,7 +923,31 @@ static int size_q_plane(ppn_engine* e) {
   rc_attr = PPN_BY_W(e->W, set_lds_attr<1>(e->lds_bytes), set_lds_attr<2>(e->lds_bytes), set_lds_attr<4>(e->lds_bytes));
   if (rc_attr) return fail(e, PPN_E_HIP, "cannot reserve %zu bytes of LDS: %s", e->lds_bytes, dev_err());
 #endif
+  setup_two_cap(e);
   return PPN_OK;
+}
+
+// Two-capacity stepping (see ppn_engine::two_cap): the small storage = the largest P = Q capacity with which four environments
+// share a CU (32 LDS granules of 1280 bytes each), if that still is a sensible margin over the base pattern.
+static void setup_two_cap(ppn_engine* e) {
+  e->two_cap = false;
+  const DevCase& d = e->dc;
+  if (!e->two_cap_allowed || e->W != 4 || d.NB <= d.nS || e->rules.lu_capacity > 0 || e->sched_prepass == 0 || !e->newton) return;
+  const size_t target = 32 * 1280;
+  if (e->lds_bytes <= target) return;
+  const int forced = e->two_cap_forced;
+  for (int ecap = forced > 0 ? forced : (d.ECAP & ~7); ecap >= e->pattern_pairs + (forced > 0 ? 0 : 8); ecap -= 8) {
+    DevCase t = d;
+    t.ECAP = ecap; t.QCAP = ecap; t.LUCAP = 2 * (t.ECAP + t.QCAP);
+    if (16L * ((long)t.ECAP + t.QCAP) >= 0xFFFFL) continue;
+    Smem tmp;
+    const size_t lds = ppn_carve(t, e->W, 1, nullptr, &tmp);
+    if (lds <= target || forced > 0) {
+      if (forced <= 0 && ecap < (int)(1.25 * e->pattern_pairs)) return;      // too tight to be worth a second launch
+      e->ecap_small = ecap; e->lds_small_cap = lds; e->two_cap = true;
+      return;
+    }
+  }
 }
 
 static int sync_chronics(ppn_engine* e) {
@@ -966,6 +1012,7 @@ static KArgs make_args(ppn_engine* e, bool sim_state) {
   a.d = e->dc;
   a.st = sim_state ? e->sim : e->st;
   a.n_steps = 1;
+  a.cap_class = -1;
   return a;
 }
 
@@ -1269,8 +1316,10 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
   int nblocks = e->batch;
   // schedule pre-pass: only where node switches can change the schedule at all (busbars beyond one per substation: the four-word
   // kernels), for the step the launch below executes first
+  const bool two_cap = e->two_cap && !simulate && n_steps == 1 && e->lds_sched <= 64 * 1024;
+  if (two_cap) a.ecap_small = e->ecap_small;
   if (e->sched_prepass && e->W == 4 && e->dc.NB > e->dc.nS && !simulate && e->lds_sched <= 64 * 1024) {
-    bool run = e->sched_prepass == 2;
+    bool run = e->sched_prepass == 2 || two_cap;      // (two-capacity stepping needs every environment's class before every step)
 #ifndef PPN_EMU
     if (!run) { const int slots_ = resident_slots_of(e); run = slots_ > 0 && (long)e->sched_rounds * slots_ <= (long)e->batch; }
 #else
@@ -1280,9 +1329,11 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     if (run && launch_sched<4>(e, a, e->batch)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
 #endif
   }
+  a.ecap_small = 0;
+  const size_t lds_step = two_cap ? e->lds_small_cap : e->lds_bytes;
 #ifndef PPN_EMU
   if (e->order_launches && !simulate && e->batch > 1024) {   // more workgroups than resident slots: hand out the long ones first
-    const int slots_ = e->persistent ? resident_slots_of(e) : 0;
+    const int slots_ = e->persistent ? resident_slots_of(e, lds_step) : 0;
     // (the throughput regime only: see K_STEP_PERSIST; not for the one-word kernels -- an IEEE-14 step is ~40 us, the trip to the
     //  position counter between two of them costs more than the workgroup launch it replaces: 37.9 vs 36.8 M at 16384)
     const bool pers = e->persistent && e->W >= 2 && n_steps == 1 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)e->batch;
@@ -1291,6 +1342,20 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     if (pers) { a.work_counter = e->d_work; a.n_work = e->batch; nblocks = e->resident_slots; }
   }
 #endif
+  if (two_cap) {
+    // the small-storage launch (class 0), then the large-storage one for whatever is left (class 1: plain form, one workgroup per
+    // environment -- those of the other class return at once)
+    KArgs as = a;
+    as.d.ECAP = e->ecap_small; as.d.QCAP = e->ecap_small; as.d.LUCAP = 4 * e->ecap_small;
+    as.cap_class = 0;
+    e->lds_override = e->lds_small_cap;
+    const int rc_s = as.work_counter ? launch<K_STEP_PERSIST>(e, as, nblocks, true) : launch<K_STEP>(e, as, nblocks, true);
+    e->lds_override = 0;
+    if (rc_s) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+    KArgs al = a;
+    al.cap_class = 1; al.perm = nullptr; al.work_counter = nullptr;
+    if (launch<K_STEP>(e, al, e->batch, false)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  } else
   if (n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, true) : (a.work_counter ? launch<K_STEP_PERSIST>(e, a, nblocks, true) : launch<K_STEP>(e, a, nblocks, true))) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   if (a.auto_reset && e->maybe_dead) {
     // environments that were already over when the step began (after ppn_reset or after steps without auto_reset) did
@@ -1589,7 +1654,7 @@ extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int
     const bool report = f == PPN_F_DONE || f == PPN_F_FLAG || f == PPN_F_ILLEGAL || f == PPN_F_REWARD || f == PPN_F_ILLEGAL_COUNTS ||
                         f == PPN_F_ACTION_SWITCHES || f == PPN_F_CASCADE_DEPTH || f == PPN_F_LINE_EVENTS || f == PPN_F_SOLVE_OUTCOME ||
                         f == PPN_F_STEP_REPORT || f == PPN_F_N_STEPS || f == PPN_F_RETURN /* counters of EXECUTED steps: a restart does not touch them */ ||
-                        (int)f == 100 /* phase counters of the profiling build */ || (int)f == 102;
+                        (int)f == 100 /* phase counters of the profiling build */ || (int)f == 102 || (int)f == 103;
     if (!report && from_simulation == 0) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   }
   FieldInfo fi; bool w;

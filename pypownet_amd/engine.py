@@ -325,6 +325,13 @@ class Engine(object):
         self._check(self._lib.ppn_read(self._h, 102, out.ctypes.data, out.nbytes, 1, 0), 'ppn_read')
         return out
 
+    def capacity_classes(self):
+        """Two-capacity stepping (four-word engines with the default matrix capacity): the class the schedule pre-pass gave every
+        environment for its last step -- 0 small storage (four environments per CU), 1 large (internal field 103)."""
+        out = np.empty(self.batch, dtype=np.uint8)
+        self._check(self._lib.ppn_read(self._h, 103, out.ctypes.data, out.nbytes, 1, 0), 'ppn_read')
+        return out
+
     def schedule_caches(self):
         """Raw schedule cache blobs of every environment (internal field 101: header, signature, index tables)."""
         n = int(self._lib.ppn_field_bytes(self._h, 101))

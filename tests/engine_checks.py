@@ -1081,3 +1081,46 @@ def check_policy_rollout_equals_stepping(lib_path, envname='default118', batch=8
     assert not a.read('ILLEGAL').any()
     a.close(); b.close()
     return acted
+
+
+def check_two_capacity_stepping(lib_path, steps=16, batch=12, solver='newton', seed=21, auto_reset=2, small_ecap=0):
+    """Two-capacity stepping (round 5: the step kernel launched for a small matrix storage -- four environments per CU -- for the
+    environments whose schedule fits it, then for the large storage for the rest) against one launch with the large storage
+    (PPN_TWO_CAP=0): every state and report field bit for bit the same under random node splitting.  small_ecap forces a small storage so
+    small that a good share of the environments needs the large one (the default one holds every topology seen so far)."""
+    import os
+    case, cfg, chronics = load_env('default118', conf={'solver': solver})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    if small_ecap:
+        os.environ['PPN_TWO_CAP_ECAP'] = str(small_ecap)
+    try:
+        a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics)
+        os.environ['PPN_TWO_CAP'] = '0'
+        b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics)
+    finally:
+        os.environ.pop('PPN_TWO_CAP', None)
+        os.environ.pop('PPN_TWO_CAP_ECAP', None)
+    for e in (a, b):
+        e.reset()
+    assert a._lib.ppn_dim(a._h, 17) > 0 and b._lib.ppn_dim(b._h, 17) == 0      # (decided once the chronics are on the device)
+    assert 0 < a._lib.ppn_dim(a._h, 18) < a._lib.ppn_dim(a._h, 7)
+    rng = np.random.default_rng(seed)
+    fields = ('VM', 'VA', 'PF', 'AMPS', 'PG', 'QG', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES',
+              'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN', 'SOFT_COUNT', 'N_SOLVES', 'N_ITERS', 'N_STEPS', 'DONE', 'FLAG', 'ILLEGAL',
+              'CASCADE_DEPTH', 'SOLVE_OUTCOME', 'BUS_TYPE', 'CHRONIC_ROW', 'REWARD', 'DEAD')
+    n_big, n_small = 0, 0
+    for t in range(steps):
+        acts = random_actions(case, rng, batch, p_node=0.85, p_line=0.3)
+        a.step(acts, auto_reset=auto_reset)
+        b.step(acts, auto_reset=auto_reset)
+        cls = a.capacity_classes()
+        n_big += int(cls.sum()); n_small += int((cls == 0).sum())
+        if auto_reset == 2 and t % 3 == 2:
+            a.sync(); b.sync()
+        for f in fields:
+            if auto_reset == 2 and f not in ('DONE', 'FLAG', 'ILLEGAL', 'REWARD', 'CASCADE_DEPTH', 'SOLVE_OUTCOME', 'N_STEPS') and t % 3 != 2:
+                continue      # (state fields settle the deferred restarts: looked at every third step only)
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
+        assert int((a.read('FLAG') == 4).sum()) == 0
+    a.close(); b.close()
+    return dict(big=n_big, small=n_small)

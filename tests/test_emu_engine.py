@@ -203,3 +203,9 @@ def test_emu_step_report_field(emu_lib):
 def test_emu_policy_rollout_equals_stepping(emu_lib):
     assert ec.check_policy_rollout_equals_stepping(emu_lib, 'default118', batch=6, n_steps=14, params=(0.9,), max_active_buses=118) > 0
     assert ec.check_policy_rollout_equals_stepping(emu_lib, 'default14_for_tests_alpha', batch=8, n_steps=30, params=(0.5,), bench_limits=False) > 0
+
+
+@pytest.mark.parametrize('small_ecap,auto_reset', [(0, 2), (664, True), (656, 2)])
+def test_emu_two_capacity_stepping(emu_lib, small_ecap, auto_reset):
+    st = ec.check_two_capacity_stepping(emu_lib, steps=14, batch=8, small_ecap=small_ecap, auto_reset=auto_reset)
+    assert st['small'] > 0 and (st['big'] > 0 or not small_ecap), st

@@ -525,3 +525,12 @@ def test_gpu_policy_rollout_equals_stepping(env, batch, steps, thr, kw):
     (ppn_rollout_policy: work items (step, environment) handed to whichever workgroup is free) -- trajectories bit for bit those of
     synchronous stepping with the same policy."""
     assert ec.check_policy_rollout_equals_stepping(HIP, env, batch=batch, n_steps=steps, params=(thr,), bench_limits=(env == 'default118'), **kw) > 0
+
+
+@pytest.mark.parametrize('small_ecap,auto_reset,batch', [(0, 2, 1024), (664, True, 256), (656, 2, 2048)])
+def test_gpu_two_capacity_stepping(small_ecap, auto_reset, batch):
+    """Round 5: the default capacity of the four-word engines -- a small-storage launch (four environments per CU) for the environments
+    whose schedule fits, a large-storage launch for the rest -- gives the states one large-storage launch gives, bit for bit; with a
+    forced tiny small storage a good share of the environments goes through the second launch."""
+    st = ec.check_two_capacity_stepping(HIP, steps=20, batch=batch, small_ecap=small_ecap, auto_reset=auto_reset)
+    assert st['small'] > 0 and (st['big'] > 0 or not small_ecap), st
