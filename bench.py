@@ -293,7 +293,7 @@ def other_configs(device, auto_reset, steps):
     add('configs[2] / configs[3] at 32768 environments on one GPU', ENV_NAME, 'newton', 32768, max(8, steps // 3), device, auto_reset,
         limits=lim, max_active=case118.nS)
     add('configs[4] share of one GPU: default118 AC Newton-Raphson, random node splitting every step, batch 1024, every busbar may '
-        'be active (W = 4 kernels, schedule rebuilt on every accepted switch); safe defaults: full Q plane, pattern capacity 2.15 x',
+        'be active (W = 4 kernels); DEFAULT capacities: two-capacity stepping (small storage 1.48 x the base pattern, four environments per CU; large storage 2.15 x for schedules that do not fit)',
         ENV_NAME, 'newton', 1024, steps, device, auto_reset, limits=lim, split=True, watch_capacity=20)
     # matrix capacity 1.5 x the base pattern instead of the default 2.15 x (tools/fill_survey.py: the largest pattern over 10^6 random
     # topologies is 1.39 x): the working set drops under 40,960 bytes = 32 LDS granules, four environments per CU instead of three
@@ -573,6 +573,32 @@ def main():
                 eng.sync()
                 out['config'][key] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - c0) / (time.perf_counter() - t_o)
                 del obs_t
+        if world == 1 and exchange is None and not args.no_rollout:
+            # CLOSED LOOP WITHOUT THE BATCH BARRIER (ppn_rollout_policy, round 5): a policy that lives on the device -- the built-in
+            # toy operator: reconnect a reconnectable line, else open the most loaded line beyond its limit -- and every environment
+            # on its own clock: work items (step, environment) go to whichever workgroup is free, trajectories bit for bit those of
+            # { ppn_policy_actions; ppn_step } round by round (tests: check_policy_rollout_equals_stepping).  Beside it: the same
+            # closed loop stepped synchronously (policy kernel + step kernel per step).  Never `value`.
+            pol_buf = torch.zeros((B, case.action_length), dtype=torch.uint8, device='cuda:%d' % local_rank)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                eng.policy_actions('line_relief', [1.0], pol_buf.data_ptr())
+                eng.step_device(pol_buf.data_ptr(), auto_reset=1)
+            eng.sync()
+            p0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+            t_p = time.perf_counter()
+            for _ in range(args.steps):
+                eng.policy_actions('line_relief', [1.0], pol_buf.data_ptr())
+                eng.step_device(pol_buf.data_ptr(), auto_reset=1)
+            eng.sync()
+            out['config']['closed_loop_device_policy_stepped_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - p0) / (time.perf_counter() - t_p)
+            eng.rollout_policy('line_relief', [1.0], 3)
+            eng.sync()
+            p0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+            t_p = time.perf_counter()
+            eng.rollout_policy('line_relief', [1.0], args.steps)
+            eng.sync()
+            out['config']['closed_loop_device_policy_rollout_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - p0) / (time.perf_counter() - t_p)
         if world == 1:
             # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
             # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel statistics, HBM / SQ counters (separate --pmc passes, as the
 # MI355X guide prescribes), the per-phase cycle profile and the bench line of the current build.  Output: gpurun_out/<tag>/
-TAG=${1:-r03}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -30,3 +30,18 @@ PPN_BENCH_CHRONICS=2 python bench.py --batch 32768 --steps 20 --warmup 3 --no-cp
 tail -1 $OUT/bench.json | cut -c1-400
 ls $OUT $OUT/stats | head -30
 # afterwards, in the development container: python tools/summarize_pmc.py $TAG  (-> profiles/)
+# ---- round 5 extras ------------------------------------------------------------------------------------------------------------
+# closed-loop device policy: stepped vs one launch (ppn_rollout_policy)
+for b in 4096 8192; do python tools/policy_rate.py $b 60 >> $OUT/policy_rate.txt 2>/dev/null; done
+# configs[4] workload: schedule pre-pass off / one wave / four waves, two-capacity stepping on / off (same box)
+for pp in 0 64 256 1; do for cfg in "1024 24 tuned" "8192 12 tuned"; do echo "PPN_SCHED_PREPASS=$pp $cfg: $(PPN_SCHED_PREPASS=$pp python tools/split_rate.py $cfg 2>/dev/null | tail -1)"; done; done > $OUT/split_prepass_ab.txt 2>&1
+for tc in 1 0; do for cfg in "1024 24 safe" "8192 12 safe"; do echo "PPN_TWO_CAP=$tc $cfg: $(PPN_TWO_CAP=$tc python tools/split_rate.py $cfg 2>/dev/null | tail -1)"; done; done > $OUT/split_two_cap_ab.txt 2>&1
+# schedule_build phase by phase: inside the step kernel (one wave), in the pre-pass (four waves / one wave)
+PPN_SCHED_PREPASS=0 PPN_TWO_CAP=0 python tools/profile_phases.py 1024 8 split > $OUT/phase_profile_split_b1024_build_in_step_kernel.txt 2>&1
+PPN_SCHED_PREPASS=256 PPN_TWO_CAP=0 python tools/profile_phases.py 1024 8 split > $OUT/phase_profile_split_b1024_prepass_4waves.txt 2>&1
+PPN_SCHED_PREPASS=64 PPN_TWO_CAP=0 python tools/profile_phases.py 1024 8 split > $OUT/phase_profile_split_b1024_prepass_1wave.txt 2>&1
+# soaks: four-word kernels under random actions (>= 10^6 solves per solver), bench workload
+python tests/tools/soak_random.py default118 newton 2048 60 6 > $OUT/soak_random_w4_newton.txt 2>&1
+python tests/tools/soak_random.py default118 fdxb 2048 60 6 > $OUT/soak_random_w4_fdxb.txt 2>&1
+python tests/tools/soak_parity.py 4096 300 20 > $OUT/soak_parity.txt 2>&1
+tail -2 $OUT/soak_random_w4_newton.txt $OUT/soak_random_w4_fdxb.txt $OUT/soak_parity.txt $OUT/policy_rate.txt
