@@ -555,6 +555,10 @@ def main():
             # CLOSED LOOP WITH THE OBSERVATION (what RunEnv.step returns, environment.py:848-866): the same step followed by the
             # observation gather (K_OBS) into a device tensor, every step -- what a policy that lives on this GPU pays.  Full
             # Observation.as_array() in float64 (4 967 values = 39.7 KB per environment) and the minimalist layout in float32.
+            # (fused restart, auto_reset = 1: looking at the state after every step settles a deferred restart with a launch of its
+            #  own -- 0.18 ms on this workload, profiles/r05_bench_rocprofv3_kernel_stats.csv -- so the deferral only pays for agents
+            #  that do not look; PPN_BENCH_OBS_AUTO_RESET=2 measures that form)
+            OBS_AR = int(os.environ.get('PPN_BENCH_OBS_AUTO_RESET', '1'))
             for key, lay, f32 in (('closed_loop_with_observation_env_steps_per_s', 'full', False),
                                   ('closed_loop_with_minimalist_f32_observation_env_steps_per_s', 'minimalist', True)):
                 n_obs = eng.observation_length(lay)
@@ -562,13 +566,13 @@ def main():
                 nb = obs_t.numel() * obs_t.element_size()
                 torch.cuda.synchronize()
                 for _ in range(3):
-                    eng.step_device(aptr, auto_reset=AUTO_RESET)
+                    eng.step_device(aptr, auto_reset=OBS_AR)
                     eng.observations_into_device(obs_t.data_ptr(), nb, layout=lay, dtype=np.float32 if f32 else np.float64)
                 eng.sync()
                 c0 = int(eng.read('N_STEPS').astype(np.int64).sum())
                 t_o = time.perf_counter()
                 for _ in range(args.steps):
-                    eng.step_device(aptr, auto_reset=AUTO_RESET)
+                    eng.step_device(aptr, auto_reset=OBS_AR)
                     eng.observations_into_device(obs_t.data_ptr(), nb, layout=lay, dtype=np.float32 if f32 else np.float64)
                 eng.sync()
                 out['config'][key] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - c0) / (time.perf_counter() - t_o)

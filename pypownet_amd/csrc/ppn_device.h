@@ -107,8 +107,11 @@ __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" :
 //   * they do NOT depend on waiting: s_waitcnt lgkmcnt(0), or vmcnt(0) lgkmcnt(0), at every phase boundary changes nothing;
 //   * they DO depend on the optimisation level: the round-2 tree passes at -O1 and -O2 and fails at -O3;
 //   * lanes are NOT found parked: -DPPN_EXEC_CHECK records EXEC != all-ones at these points -- zero events -- and setting EXEC at
-//     the round-2 tree's loop heads does not cure it.  For the rollout kernel the cure therefore is (b): code motion across the
-//     loop head, not a lost EXEC mask;
+//     the round-2 tree's loop heads does not cure it.  For the rollout kernel ANY volatile statement at the loop head is the cure
+//     (an empty one with a memory clobber, or the EXEC write without the clobber): it pins the loop's shape for the code generator.
+//     Bisecting the LLVM pass pipeline puts the flip at one `simplifycfg` run on the kernel -- a neutral IR clean-up: the faulty
+//     step is downstream (instruction selection / structurisation / allocation of a 29 000-instruction kernel with 500-690 spilled
+//     scalars), not found;
 //   * the lane-serial emulation cannot see them in any lane order (tests/test_emu_lane_order.py): not an ordering assumption of
 //     the kernels' own.
 // It stays at the loop heads as a hardening: one scalar instruction where the phase boundary is a compiler fence anyway.
