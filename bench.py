@@ -404,33 +404,45 @@ def main():
         # stream waits instead of host synchronisations, two buffer sets alternating: the host only enqueues, step t + 1's scatter is
         # queued while step t's gather is in flight (round 4: two host synchronisations + three reads + a pack per step)
         ext = torch.cuda.ExternalStream(eng.stream_ptr(), device=dev)
-        xb = [dict(act=torch.zeros_like(actions), res=torch.zeros((B, 3), dtype=torch.float64, device=dev),
+        xb = [dict(act=torch.zeros_like(actions), res=torch.zeros((B, 3), dtype=torch.float64, device=dev), free=None,
                    out=([torch.empty((B, 3), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None)) for _ in range(2)]
         if on_host and rank == 0:
             for b_ in xb:
                 b_['out'] = [t_.cpu() for t_ in b_['out']]
         turn = [0]
+        # the gather runs on a communicator and a stream of its own: the scatter of step t + 1 (default group, scatter stream) and
+        # step t + 1 itself then do not queue behind the gather of step t -- what a controller whose policy does not need step t's
+        # report to choose the actions of step t + 1 (the do-nothing controller of this bench) can overlap
+        g_gather = dist.new_group(backend=backend) if not on_host else None
+        s_scatter, s_gather = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if not on_host else (None, None)
 
         def exchange():
             b_ = xb[turn[0]]
             turn[0] ^= 1
-            cur = torch.cuda.current_stream()
             if on_host:
+                cur = torch.cuda.current_stream()
                 recv = torch.empty(actions.shape, dtype=actions.dtype)
                 dist.scatter(recv, all_actions, src=0)
                 b_['act'].copy_(recv)
-            else:
-                cur.wait_stream(ext)
-                dist.scatter(b_['act'], all_actions, src=0)            # [B x action_length] u8 to every rank
-            ext.wait_stream(cur)
-            eng.step_device(b_['act'].data_ptr(), auto_reset=AUTO_RESET)
-            eng.read_into_device('STEP_REPORT', b_['res'].data_ptr(), 24 * B)
-            if on_host:
+                ext.wait_stream(cur)
+                eng.step_device(b_['act'].data_ptr(), auto_reset=AUTO_RESET)
+                eng.read_into_device('STEP_REPORT', b_['res'].data_ptr(), 24 * B)
                 eng.wait()
                 dist.gather(b_['res'].cpu(), b_['out'], dst=0)
-            else:
-                cur.wait_stream(ext)
-                dist.gather(b_['res'], b_['out'], dst=0)      # 24 B per environment back to the controller
+                return
+            with torch.cuda.stream(s_scatter):
+                if b_['free'] is not None:
+                    s_scatter.wait_event(b_['free'])       # this buffer set's gather (two steps ago) is through -- and so is the step before it
+                dist.scatter(b_['act'], all_actions, src=0)            # [B x action_length] u8 to every rank
+                ev_sc = s_scatter.record_event()
+            ext.wait_event(ev_sc)                          # the engine's stream waits for the scatter: an event, no host synchronisation
+            eng.step_device(b_['act'].data_ptr(), auto_reset=AUTO_RESET)
+            eng.read_into_device('STEP_REPORT', b_['res'].data_ptr(), 24 * B)
+            ev_st = ext.record_event()
+            with torch.cuda.stream(s_gather):
+                s_gather.wait_event(ev_st)
+                dist.gather(b_['res'], b_['out'], dst=0, group=g_gather)      # 24 B per environment back to the controller
+                b_['free'] = s_gather.record_event()
         exchange()
 
     eng.sync()
