@@ -180,6 +180,24 @@ class BatchedRunEnv(object):
             e.rollout_device(t.data_ptr(), n_steps, per_step_actions=per_step, auto_reset=auto_reset)
         return e.read('RETURN'), e.read('DONE').astype(bool), e.read('FLAG'), e.read('N_STEPS')
 
+    def policy_actions(self, policy='line_relief', params=(1.0,)):
+        """The built-in device policy's choice for the CURRENT state of every environment of this shard (include/ppn.h,
+        ppn_policy_actions) as a torch CUDA uint8 tensor [batch x action_length] -- ready for ``step``."""
+        import torch
+        out = torch.empty((self.batch, self.action_length), dtype=torch.uint8, device='cuda:%d' % self.device)
+        self._sync_torch(out)
+        self.engine.policy_actions(policy, list(params), out.data_ptr())
+        self.engine.wait()
+        return out
+
+    def rollout_policy(self, n_steps, policy='line_relief', params=(1.0,)):
+        """``n_steps`` closed-loop steps of a built-in device policy in ONE launch, every environment on its own clock (include/ppn.h,
+        ppn_rollout_policy): same trajectories as ``step(policy_actions())`` round by round with the fused restart.  Returns
+        (cumulative reward since reset [batch], done / flag of the LAST step, steps executed since reset [batch])."""
+        e = self.engine
+        e.rollout_policy(policy, list(params), int(n_steps))
+        return e.read('RETURN'), e.read('DONE').astype(bool), e.read('FLAG'), e.read('N_STEPS')
+
     def search(self, candidate_actions, want_obs=False):
         """Topology-action search (what the reference's search agents do with one ``simulate`` call per candidate,
         pypownet/agent.py:161-325): ``candidate_actions`` uint8 [batch x K x action_length], host array or device tensor; every

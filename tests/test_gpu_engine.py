@@ -534,3 +534,25 @@ def test_gpu_two_capacity_stepping(small_ecap, auto_reset, batch):
     forced tiny small storage a good share of the environments goes through the second launch."""
     st = ec.check_two_capacity_stepping(HIP, steps=20, batch=batch, small_ecap=small_ecap, auto_reset=auto_reset)
     assert st['small'] > 0 and (st['big'] > 0 or not small_ecap), st
+
+
+def test_gpu_batched_policy_api():
+    """BatchedRunEnv.policy_actions / rollout_policy: the device policy stepped through the tensor API equals its one-launch rollout."""
+    import torch
+    from pypownet_amd.batched import BatchedRunEnv
+    from helpers import ENVS
+    envdir = os.path.join(ENVS, 'default14')
+    a = BatchedRunEnv(envdir, 'level0', 96, device=0, config_overrides={'solver': 'newton'})
+    b = BatchedRunEnv(envdir, 'level0', 96, device=0, config_overrides={'solver': 'newton'})
+    for e in (a, b):
+        e.reset()
+        e.engine.process_game_over()
+    for _ in range(25):
+        acts = a.policy_actions('line_relief', (0.6,))
+        assert acts.is_cuda and tuple(acts.shape) == (96, a.action_length) and int(acts.sum(dim=1).max()) <= 1
+        a.step(acts, auto_reset=1, want_obs=False)
+    ret, done, flag, nst = b.rollout_policy(25, 'line_relief', (0.6,))
+    assert np.array_equal(nst, a.engine.read('N_STEPS')) and int(nst.sum()) == 96 * 25
+    assert np.array_equal(ret, a.engine.read('RETURN')) and np.array_equal(flag, a.engine.read('FLAG'))
+    for f in ('VM', 'LINES_STATUS', 'RECONNECTABLE', 'CHRONIC_ROW'):
+        assert np.array_equal(a.engine.read(f), b.engine.read(f), equal_nan=True), f
