@@ -354,6 +354,7 @@ struct Smem {
   u64* adjF;                                   // schedule_build scratch (view of R, with adj0)
   u16 *yptr, *scn, *moffq, *toffq, *rowptr, *lvlp, *lvlm, *lvlt, *int2row, *ediag;
   u8 *pvl, *kq, *mem, *mown;
+  unsigned *pfx0, *pfxF;              // schedule_build: per row, the number of set bits below word 1 | 2 | 3 of its adj0 / adjF bitset (one byte each)
   // compact carve only (is_action_valid), schedule pre-pass
   u8* act;
   int* scr;                           // schedule pre-pass only: exchange words of the workgroup-wide collectives (sb_scan_u16, sb_sum_i)
@@ -414,6 +415,7 @@ PPN_HD size_t ppn_carve(const DevCase& d, int W, int NT, unsigned char* base, Sm
   PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
   PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(ediag, u16, NB * 2)
   PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
+  PPN_TAKE(pfx0, unsigned, NB * 4) PPN_TAKE(pfxF, unsigned, NB * 4)
   const size_t build_end = o;
   // view: setup scratch of a solve (adj0 shared with the view above), then the bus vectors
   o = after_adj0;
@@ -450,6 +452,7 @@ PPN_HD size_t ppn_carve_sched(const DevCase& d, int W, unsigned char* base, Smem
   PPN_TAKE(rowptr, u16, (NB + 1) * 2) PPN_TAKE(lvlp, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(lvlm, u16, ((size_t)d.nlev + 1) * 2)
   PPN_TAKE(lvlt, u16, ((size_t)d.nlev + 1) * 2) PPN_TAKE(int2row, u16, NB * 2) PPN_TAKE(ediag, u16, NB * 2)
   PPN_TAKE(pvl, u8, NB) PPN_TAKE(kq, u8, NB) PPN_TAKE(mem, u8, (size_t)d.MCAP) PPN_TAKE(mown, u8, (size_t)d.MCAP)
+  PPN_TAKE(pfx0, unsigned, NB * 4) PPN_TAKE(pfxF, unsigned, NB * 4)
 #undef PPN_TAKE
   S.st = nullptr; S.over = nullptr; S.amps = nullptr; S.nv = nullptr; S.qrel = nullptr; S.vc = nullptr; S.rhs = nullptr; S.zero = nullptr;
   S.lu = nullptr; S.tinv = nullptr;
