@@ -273,6 +273,38 @@ OTHER_CONFIG_KEYS = ['cfg1_d14_nr_b1024', 'cfg1_d14_nr_b16384', 'cfg2_d118_fdxb_
                      'cfg4_split_b1024_safe', 'cfg4_split_b1024_tuned', 'cfg4_split_b8192_tuned', 'cfg2_rule110_b4096']
 
 
+def search_rate(device, batch=1024, k=8, rounds=8):
+    """Topology-action search (ppn_simulate_candidates): k node-splitting candidates per environment forked from its
+    current state and simulated in one call, followed by a do-nothing step -- a search agent's round; simulated candidates per second."""
+    import torch
+    from pypownet_amd.engine import Engine
+    case, conf, chronics = load_env_fixture(ENV_NAME, 'newton')
+    eng = Engine(case, conf, batch, device=device, chronics=chronics, thermal_limits=bench_limits(case))
+    slots, t0 = env_assignment(0, batch, chronics)
+    eng.reset(chronic_slot=slots, t0=t0)
+    rng = np.random.default_rng(5)
+    cands = np.zeros((batch * k, case.action_length), dtype=np.uint8)
+    for c in range(batch * k):
+        idx = np.asarray(case.mapping_array[int(rng.integers(case.nS))], dtype=int)
+        cands[c, idx] = rng.integers(0, 2, size=len(idx))
+    d_c = torch.from_numpy(cands).to('cuda:%d' % device)
+    act = torch.zeros((batch, case.action_length), dtype=torch.uint8, device='cuda:%d' % device)
+    env_ids = np.repeat(np.arange(batch, dtype=np.int32), k)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        eng.simulate_candidates_device(d_c.data_ptr(), env_ids)
+        eng.step_device(act.data_ptr(), auto_reset=1)
+    eng.sync()
+    t = time.perf_counter()
+    for _ in range(rounds):
+        eng.simulate_candidates_device(d_c.data_ptr(), env_ids)
+        eng.step_device(act.data_ptr(), auto_reset=1)
+    eng.sync()
+    el = time.perf_counter() - t
+    eng.close()
+    return batch * k * rounds / el
+
+
 def other_configs(device, auto_reset, steps):
     """BASELINE.json configs[1], configs[2] with the reference's solver, the one-GPU share of configs[4], the large-batch point
     and the SURVEY.md 8d limit rule of configs[2] -- one entry each in the bench line (`other_configs`)."""
@@ -639,6 +671,10 @@ def main():
                 flat[key + '_Msteps'] = round(entry['env_steps_per_s'] / 1e6, 4)
                 flat[key + '_frac'] = round(entry['roofline_frac'], 4)
                 flat[key + '_kernel_ms'] = round(entry['step_kernel_ms'], 4)
+            try:      # topology-action search on the configs[4] engine: M simulated node-splitting candidates per second (1024 x 8)
+                flat['cfg4_search_1024x8_Mcandidates'] = round(search_rate(local_rank) / 1e6, 4)
+            except Exception as ex:
+                flat['cfg4_search_error'] = str(ex)[:100]
             out['other_configs'] = flat
         if world == 1 and not args.no_cpu_baseline:
             try:

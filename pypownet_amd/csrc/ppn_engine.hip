@@ -1527,6 +1527,23 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
   KArgs a = make_args(e, false);
   a.st = e->cand;
   a.actions = dact; a.sim = 1; a.auto_reset = 0;
+  if (e->two_cap && e->lds_sched <= 64 * 1024) {
+    // two-capacity stepping for the candidates as well (round 5): the pre-pass builds every candidate's schedule in its slot's cache
+    // and classes it; the small-storage launch plays four candidates per CU, the large-storage one whatever does not fit
+#ifndef PPN_ONLY_W1
+    a.ecap_small = e->ecap_small;
+    if (launch_sched<4>(e, a, n)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
+    a.ecap_small = 0;
+#endif
+    KArgs as = a;
+    as.d.ECAP = e->ecap_small; as.d.QCAP = e->ecap_small; as.d.LUCAP = 4 * e->ecap_small;
+    as.cap_class = 0;
+    e->lds_override = e->lds_small_cap;
+    const int rc_s = launch<K_STEP>(e, as, n);
+    e->lds_override = 0;
+    if (rc_s) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+    a.cap_class = 1;
+  }
   if (launch<K_STEP>(e, a, n)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   return PPN_OK;
 }
