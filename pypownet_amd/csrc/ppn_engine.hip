@@ -932,7 +932,7 @@ static int size_q_plane(ppn_engine* e) {
 static void setup_two_cap(ppn_engine* e) {
   e->two_cap = false;
   const DevCase& d = e->dc;
-  if (!e->two_cap_allowed || e->W != 4 || d.NB <= d.nS || e->rules.lu_capacity > 0 || e->sched_prepass == 0 || !e->newton) return;
+  if (!e->two_cap_allowed || e->W != 4 || d.NB <= d.nS || e->rules.lu_capacity > 0 || e->sched_prepass == 0 || e->dc.R.mode == 1) return;
   const size_t target = 32 * 1280;
   if (e->lds_bytes <= target) return;
   const int forced = e->two_cap_forced;
@@ -941,7 +941,7 @@ static void setup_two_cap(ppn_engine* e) {
     t.ECAP = ecap; t.QCAP = ecap; t.LUCAP = 2 * (t.ECAP + t.QCAP);
     if (16L * ((long)t.ECAP + t.QCAP) >= 0xFFFFL) continue;
     Smem tmp;
-    const size_t lds = ppn_carve(t, e->W, 1, nullptr, &tmp);
+    const size_t lds = ppn_carve(t, e->W, e->newton ? 1 : 0, nullptr, &tmp);
     if (lds <= target || forced > 0) {
       if (forced <= 0 && ecap < (int)(1.25 * e->pattern_pairs)) return;      // too tight to be worth a second launch
       e->ecap_small = ecap; e->lds_small_cap = lds; e->two_cap = true;

@@ -209,3 +209,8 @@ def test_emu_policy_rollout_equals_stepping(emu_lib):
 def test_emu_two_capacity_stepping(emu_lib, small_ecap, auto_reset):
     st = ec.check_two_capacity_stepping(emu_lib, steps=14, batch=8, small_ecap=small_ecap, auto_reset=auto_reset)
     assert st['small'] > 0 and (st['big'] > 0 or not small_ecap), st
+
+
+def test_emu_two_capacity_stepping_fast_decoupled(emu_lib):
+    st = ec.check_two_capacity_stepping(emu_lib, steps=14, batch=8, small_ecap=660, auto_reset=True, solver='fdxb')
+    assert st['small'] > 0 and st['big'] > 0, st

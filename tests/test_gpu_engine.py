@@ -556,3 +556,10 @@ def test_gpu_batched_policy_api():
     assert np.array_equal(ret, a.engine.read('RETURN')) and np.array_equal(flag, a.engine.read('FLAG'))
     for f in ('VM', 'LINES_STATUS', 'RECONNECTABLE', 'CHRONIC_ROW'):
         assert np.array_equal(a.engine.read(f), b.engine.read(f), equal_nan=True), f
+
+
+def test_gpu_two_capacity_stepping_fast_decoupled():
+    st = ec.check_two_capacity_stepping(HIP, steps=20, batch=512, small_ecap=660, auto_reset=2, solver='fdxb')
+    assert st['small'] > 0 and st['big'] > 0, st
+    st = ec.check_two_capacity_stepping(HIP, steps=12, batch=1024, small_ecap=0, auto_reset=2, solver='fdxb')
+    assert st['small'] > 0, st

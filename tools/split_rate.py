@@ -16,7 +16,7 @@ def main():
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     tuned = (sys.argv[3] if len(sys.argv) > 3 else 'tuned') == 'tuned'
     case, _, _ = bench.load_env_fixture(bench.ENV_NAME, 'newton')
-    out = bench.side_config('configs[4] workload', bench.ENV_NAME, 'newton', B, K, 0, 2, limits=bench.bench_limits(case), split=True,
+    out = bench.side_config('configs[4] workload', bench.ENV_NAME, os.environ.get('PPN_SPLIT_SOLVER', 'newton'), B, K, 0, 2, limits=bench.bench_limits(case), split=True,
                             lu_capacity=3976 if tuned else 0, q_plane_auto=1 if tuned else 0)
     out['sched_prepass'] = os.environ.get('PPN_SCHED_PREPASS', '1') != '0'
     print(json.dumps(out))
