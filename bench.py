@@ -351,10 +351,16 @@ def main():
     ap.add_argument('--no-rollout', action='store_true',
                     help='skip the open-loop rollout side figure (profiling passes: its one long launch runs the same kernel symbol as '
                          'the timed step launches and would skew per-launch averages)')
+    ap.add_argument('--headline-only', action='store_true',
+                    help='only the timed headline loop: no closed-loop / host-boundary / rollout side figures, no other configurations, no '
+                         'CPU baseline (profiling passes: every launch of the step kernel symbol then is a launch of the timed region or '
+                         'its warm-up)')
     ap.add_argument('--single-controller', action='store_true',
                     help="BASELINE.json configs[3]'s exchange variant: every step rank 0 scatters the actions of ALL "
                          'environments and gathers (done, flag, reward) over RCCL; default: policy per GPU, no collective')
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_rollout = args.no_other_configs = args.no_cpu_baseline = True
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # launched bare (`python bench.py --gpus N`): spawn the N ranks ourselves, one per GPU, the way the driver's launcher
@@ -595,7 +601,7 @@ def main():
             el_r = time.perf_counter() - t_r
             r1 = int(eng.read('N_STEPS').astype(np.int64).sum())
             out['config']['open_loop_rollout_env_steps_per_s'] = (r1 - r0) / el_r      # (ppn_rollout, open-loop agents only; not the headline)
-        if world == 1 and exchange is None:
+        if world == 1 and exchange is None and not args.headline_only:
             # CLOSED LOOP WITH THE OBSERVATION (what RunEnv.step returns, environment.py:848-866): the same step followed by the
             # observation gather (K_OBS) into a device tensor, every step -- what a policy that lives on this GPU pays.  Full
             # Observation.as_array() in float64 (4 967 values = 39.7 KB per environment) and the minimalist layout in float32.
@@ -647,7 +653,7 @@ def main():
             eng.rollout_policy('line_relief', [1.0], args.steps)
             eng.sync()
             out['config']['closed_loop_device_policy_rollout_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - p0) / (time.perf_counter() - t_p)
-        if world == 1:
+        if world == 1 and not args.headline_only:
             # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
             # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`
             host_actions = np.zeros((B, case.action_length), dtype=np.uint8)

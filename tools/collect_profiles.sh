@@ -6,7 +6,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-rollout"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --headline-only"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- $BENCH > /dev/null 2>&1
@@ -44,4 +44,4 @@ PPN_SCHED_PREPASS=64 PPN_TWO_CAP=0 python tools/profile_phases.py 1024 8 split >
 python tests/tools/soak_random.py default118 newton 2048 60 6 > $OUT/soak_random_w4_newton.txt 2>&1
 python tests/tools/soak_random.py default118 fdxb 2048 60 6 > $OUT/soak_random_w4_fdxb.txt 2>&1
 python tests/tools/soak_parity.py 4096 300 20 > $OUT/soak_parity.txt 2>&1
-tail -2 $OUT/soak_random_w4_newton.txt $OUT/soak_random_w4_fdxb.txt $OUT/soak_parity.txt $OUT/policy_rate.txt
+tail -n 2 $OUT/soak_random_w4_newton.txt $OUT/soak_random_w4_fdxb.txt $OUT/soak_parity.txt $OUT/policy_rate.txt

@@ -37,7 +37,7 @@ def main():
     q, nq = per_launch(os.path.join(src, 'pmc_sq', 'p_counter_collection.csv'))
     hbm = (2 * f['FETCH_SIZE'] + w['WRITE_SIZE']) * 1024
     out = {
-        'command': 'rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline '
+        'command': 'rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 20 --warmup 3 --headline-only '
                    '(one pass per counter group, tools/collect_profiles.sh)',
         'kernel': KERNEL + ' = K_STEP, W=2 (IEEE-118, 118 active buses), Newton flavour, batch %d environments per launch' % BATCH,
         'launches_averaged': {'fetch': nf, 'write': nw, 'sq': nq},
