@@ -173,6 +173,8 @@ static T* dalloc(ppn_engine* e, size_t n) {
 // kernels are instantiated)
 #ifdef PPN_ONLY_W1
 #define PPN_BY_W(w_, x1, x2, x4) (x1)
+#elif defined(PPN_ONLY_W2)      // (developer builds for same-box A/B measurements of the headline kernels: two-word kernels only)
+#define PPN_BY_W(w_, x1, x2, x4) (x2)
 #else
 #define PPN_BY_W(w_, x1, x2, x4) ((w_) == 1 ? (x1) : ((w_) == 2 ? (x2) : (x4)))
 #endif
@@ -264,6 +266,8 @@ template <int KIND>
 static int launch(ppn_engine* e, const KArgs& a, int nblocks, bool timed = false) {
 #ifdef PPN_ONLY_W1      // (developer builds for compiler bisection, tools/ubench/: the one-word kernels only)
   return e->W == 1 ? launch_nt<1, KIND>(e, a, nblocks, timed) : -1;
+#elif defined(PPN_ONLY_W2)
+  return e->W == 2 ? launch_nt<2, KIND>(e, a, nblocks, timed) : -1;
 #else
   switch (e->W) {
     case 1: return launch_nt<1, KIND>(e, a, nblocks, timed);
@@ -1325,7 +1329,7 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
 #else
     run = true;      // (the emulation build always runs it: the tests exercise the code)
 #endif
-#ifndef PPN_ONLY_W1
+#if !defined(PPN_ONLY_W1) && !defined(PPN_ONLY_W2)
     if (run && launch_sched<4>(e, a, e->batch)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
 #endif
   }
@@ -1530,7 +1534,7 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
   if (e->two_cap && e->lds_sched <= 64 * 1024) {
     // two-capacity stepping for the candidates as well (round 5): the pre-pass builds every candidate's schedule in its slot's cache
     // and classes it; the small-storage launch plays four candidates per CU, the large-storage one whatever does not fit
-#ifndef PPN_ONLY_W1
+#if !defined(PPN_ONLY_W1) && !defined(PPN_ONLY_W2)
     a.ecap_small = e->ecap_small;
     if (launch_sched<4>(e, a, n)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
     a.ecap_small = 0;

@@ -45,3 +45,7 @@ python tests/tools/soak_random.py default118 newton 2048 60 6 > $OUT/soak_random
 python tests/tools/soak_random.py default118 fdxb 2048 60 6 > $OUT/soak_random_w4_fdxb.txt 2>&1
 python tests/tools/soak_parity.py 4096 300 20 > $OUT/soak_parity.txt 2>&1
 tail -n 2 $OUT/soak_random_w4_newton.txt $OUT/soak_random_w4_fdxb.txt $OUT/soak_parity.txt $OUT/policy_rate.txt
+# anatomy of the synchronous headline: which environments end a launch, environments per CU, one environment per CU
+python tests/tools/chain_lengths.py 2>&1 | grep -v Warn > $OUT/chain_lengths.txt
+for pad in 0 3500 9000 17000 30000; do echo "PPN_LDS_PAD=$pad: $(PPN_LDS_PAD=$pad python tests/tools/lib_compare.py default118 newton 4096 60 default 2>/dev/null | tail -1)"; done > $OUT/occupancy_sweep.txt
+python tools/profile_phases.py 256 10 > $OUT/phase_profile_b256_one_env_per_cu.txt 2>&1
