@@ -142,6 +142,48 @@ def check_hard_overflow_scenario(lib_path, solver):
     assert list(eng.read('LINES_STATUS')[0]) == [1] * 20
 
 
+# K12 -- Agent_test_Loss_Error (reference tests/test_core.py:519-606, 1200-1230): on default14_for_tests the observations of the
+# first three agent steps must show total production - total consumption within 1e-3 MW of what the chronic rows 1..3 imply
+# (the chronic's slack column was written from a solved state, so this is a numeric known answer for the loss total that the
+# reference's own test holds).  The expected numbers as the reference's test spells them out (float32 values of those rows):
+K12_EXPECTED_PRODS = [[123.370285, 49.144115, 32.21891, 38.52085, 35.704945],
+                      [104.072556, 43.576332, 31.90516, 32.831142, 32.747932],
+                      [134.51176, 56.608887, 0.0, 0.0, 46.029488]]
+K12_EXPECTED_LOADS = [[25.629642, 97.45528, 49.735317, 8.250563, 10.010641, 30.2604, 9.736532, 3.3486228, 7.0213113, 16.209476, 16.188494],
+                      [21.07166, 87.22948, 43.29531, 6.9710474, 10.483086, 28.114975, 10.368015, 3.0358257, 5.108532, 12.720526, 12.9846325],
+                      [18.838198, 86.235115, 44.783886, 6.563092, 9.875335, 24.161335, 6.824309, 3.2030978, 4.8327637, 12.320875, 13.072087]]
+
+
+def k12_expected_losses():
+    return [float(np.sum(p_)) - float(np.sum(l_)) for p_, l_ in zip(K12_EXPECTED_PRODS, K12_EXPECTED_LOADS)]
+
+
+def check_loss_error_scenario(lib_path, solver='fdxb'):
+    """K12 through the engine: WrappedRunner's initial process_game_over, then three do-nothing steps; the observation the agent
+    sees at steps 1, 2, 3 (= the state after process_game_over, after step 1, after step 2)."""
+    env = 'default14_for_tests'
+    eng, case, cfg, chronics = make_engine(lib_path, env, 1, conf={'solver': solver})
+    eng.reset()
+    _force_game_over(eng)
+    exp = k12_expected_losses()
+    diffs = []
+    for i in range(3):
+        pg, pd = eng.read('PG')[0], eng.read('PD')[0]
+        diffs.append(float(pg.sum() - pd.sum()) - exp[i])
+        assert abs(diffs[-1]) < 1e-3, (i + 1, diffs)
+        # (and the chronic passthrough behind it: every non-slack production and every load is the float32 chronic value)
+        assert np.allclose(np.delete(pg, case_slack_prod(case)), np.delete(np.asarray(K12_EXPECTED_PRODS[i]), case_slack_prod(case)), rtol=0, atol=1e-5)
+        assert np.allclose(pd, K12_EXPECTED_LOADS[i], rtol=0, atol=1e-5)
+        eng.step(do_nothing(case)[None, :])
+        assert int(eng.read('FLAG')[0]) == 0 and not eng.read('DONE')[0]
+    return diffs
+
+
+def case_slack_prod(case):
+    """Index of the production at the reference bus of the case file."""
+    return int(np.where(np.asarray(case.gen_sub) == case.slack_sub)[0][0])
+
+
 def check_soft_overflow_scenario(lib_path, solver='fdxb'):
     """K2 (reference tests/test_core.py:720-738, 784-811, 1322-1328) through the engine: default14_for_tests_alpha, line 6 has a
     300 A limit, breaks after 2 consecutive overflowed steps and stays broken for 2: on at steps 9 and 10, off at 11 and 12,

@@ -43,6 +43,11 @@ def test_emu_hard_overflow_scenario(emu_lib, solver):
 
 
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_emu_k12_loss_error(emu_lib, solver):
+    ec.check_loss_error_scenario(emu_lib, solver)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_emu_k3_node_splitting_all_substations(emu_lib, solver):
     nodes = list(range(1, 15))
     flags = ec.check_topology_scenarios(emu_lib, 'default14_for_tests_alpha', nodes, 7, _basic_topology_policy, solver)

@@ -31,6 +31,12 @@ def test_gpu_hard_overflow_scenario(solver):
 
 
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_k12_loss_error(solver):
+    """The reference's own numeric known answer (tests/test_core.py:519-606): loss totals of three steps within 1e-3 MW."""
+    ec.check_loss_error_scenario(HIP, solver)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_gpu_k3_node_splitting_all_substations(solver):
     nodes = list(range(1, 15))
     flags = ec.check_topology_scenarios(HIP, 'default14_for_tests_alpha', nodes, 7, _basic_topology_policy, solver)
