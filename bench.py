@@ -608,9 +608,29 @@ def main():
             # (fused restart, auto_reset = 1: looking at the state after every step settles a deferred restart with a launch of its
             #  own -- 0.18 ms on this workload, profiles/r05_bench_rocprofv3_kernel_stats.csv -- so the deferral only pays for agents
             #  that do not look; PPN_BENCH_OBS_AUTO_RESET=2 measures that form)
+            # Since round 5 in ONE launch (ppn_step_observe: every environment's workgroup writes its row right behind its step);
+            # the two-launch form (ppn_step, then ppn_read_observation) is measured beside it.
             OBS_AR = int(os.environ.get('PPN_BENCH_OBS_AUTO_RESET', '1'))
             for key, lay, f32 in (('closed_loop_with_observation_env_steps_per_s', 'full', False),
                                   ('closed_loop_with_minimalist_f32_observation_env_steps_per_s', 'minimalist', True)):
+                if OBS_AR != 1:
+                    break
+                n_obs = eng.observation_length(lay)
+                obs_t = torch.empty((B, n_obs), dtype=torch.float32 if f32 else torch.float64, device='cuda:%d' % local_rank)
+                nb = obs_t.numel() * obs_t.element_size()
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    eng.step_observe_device(aptr, obs_t.data_ptr(), nb, auto_reset=True, layout=lay, dtype=np.float32 if f32 else np.float64)
+                eng.sync()
+                c0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+                t_o = time.perf_counter()
+                for _ in range(args.steps):
+                    eng.step_observe_device(aptr, obs_t.data_ptr(), nb, auto_reset=True, layout=lay, dtype=np.float32 if f32 else np.float64)
+                eng.sync()
+                out['config'][key] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - c0) / (time.perf_counter() - t_o)
+                del obs_t
+            for key, lay, f32 in (('closed_loop_with_observation_two_launches_env_steps_per_s', 'full', False),
+                                  ('closed_loop_with_minimalist_f32_observation_two_launches_env_steps_per_s', 'minimalist', True)):
                 n_obs = eng.observation_length(lay)
                 obs_t = torch.empty((B, n_obs), dtype=torch.float32 if f32 else torch.float64, device='cuda:%d' % local_rank)
                 nb = obs_t.numel() * obs_t.element_size()

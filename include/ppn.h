@@ -243,6 +243,15 @@ int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* c
  * ILLEGAL, ILLEGAL_COUNTS, ACTION_SWITCHES, REWARD, CASCADE_DEPTH, LINE_EVENTS, SOLVE_OUTCOME, N_STEPS, RETURN. */
 int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
              int32_t auto_reset);
+/* RunEnv.step as the reference returns it (environment.py:848-874: the step AND the observation): ppn_step followed by
+ * ppn_read_observation(layout, as_f32, ..., to_host = 0) in ONE launch -- every environment's workgroup writes its row of
+ * Observation.as_array() (layouts and element types of ppn_read_observation) into obs_device right behind its step, so the gather
+ * costs no launch of its own and rides in the part of the launch where most of the machine waits for the longest cascade.  Same
+ * rows, bit for bit, as the two calls.  obs_device: DEVICE memory, bytes >= batch x ppn_observation_length(layout) x element size.
+ * auto_reset 0 or 1 (1: the row of an environment that ended shows the restarted episode, as after ppn_step(auto_reset = 1));
+ * a deferred restart (2) is refused: PPN_E_INVALID. */
+int ppn_step_observe(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t auto_reset,
+                     int32_t layout, int32_t as_f32, void* obs_device, size_t bytes);
 /* Open-loop rollout: n_steps consecutive Game.step calls of every environment in ONE launch, for callers whose actions do not
  * depend on the observations in between -- the reference's Runner.loop under a DoNothing agent (pypownet/runner.py:105-131,
  * agent.py:40-57), a recorded action file replayed (agent.py ActIOnManager), a planned switching sequence being evaluated.

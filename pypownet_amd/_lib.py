@@ -82,7 +82,7 @@ EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limit
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
            'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays', 'ppn_rollout',
-           'ppn_policy_actions', 'ppn_rollout_policy']
+           'ppn_policy_actions', 'ppn_rollout_policy', 'ppn_step_observe']
 
 
 def _preload_torch_hip_runtime():
@@ -177,6 +177,8 @@ def bind_signatures(lib, full_abi=True):
         lib.ppn_policy_actions.restype = C.c_int
         lib.ppn_rollout_policy.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_int32]
         lib.ppn_rollout_policy.restype = C.c_int
+        lib.ppn_step_observe.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t]
+        lib.ppn_step_observe.restype = C.c_int
     lib.ppn_stream.argtypes = [vp]
     lib.ppn_stream.restype = vp
     lib.ppn_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

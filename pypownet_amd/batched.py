@@ -98,7 +98,8 @@ class BatchedRunEnv(object):
             x = (x != 0).to(torch.uint8)
         return x.contiguous()
 
-    def _device_results(self, want_obs, simulation=False, layout='full', obs_dtype=None):
+    def _device_results(self, want_obs, simulation=False, layout='full', obs_dtype=None, obs=None):
+        """``obs``: the observation tensor the step kernel has already filled (ppn_step_observe) -- nothing is gathered then."""
         import torch
         e = self.engine
         rows = e._n_candidates if int(simulation) == 2 else self.batch
@@ -111,8 +112,7 @@ class BatchedRunEnv(object):
         e.read_into_device('FLAG', flag.data_ptr(), 4 * flag.numel(), simulation=simulation)
         e.read_into_device('ILLEGAL', ill.data_ptr(), 4 * ill.numel(), simulation=simulation)
         e.read_into_device('REWARD', rew.data_ptr(), 8 * rew.numel(), simulation=simulation)
-        obs = None
-        if want_obs:
+        if want_obs and obs is None:
             tdt = torch.float32 if self._is_f32(obs_dtype) else torch.float64
             obs = torch.empty((rows, e.observation_length(layout)), dtype=tdt, device=dev)
             e.observations_into_device(obs.data_ptr(), obs.numel() * obs.element_size(), simulation=simulation, layout=layout,
@@ -149,8 +149,17 @@ class BatchedRunEnv(object):
             return obs, done.astype(bool), flag, ill
         assert tuple(t.shape) == (self.batch, self.action_length)
         self._sync_torch(t)
-        self.engine.step_device(t.data_ptr(), auto_reset=auto_reset)
-        obs, done, flag, ill, _ = self._device_results(want_obs, layout=layout, obs_dtype=obs_dtype)
+        obs = None
+        if want_obs and int(auto_reset) in (0, 1):
+            # what RunEnv.step returns in ONE launch: every environment's workgroup writes its observation row behind its step
+            import torch
+            tdt = torch.float32 if self._is_f32(obs_dtype) else torch.float64
+            obs = torch.empty((self.batch, self.engine.observation_length(layout)), dtype=tdt, device='cuda:%d' % self.device)
+            self.engine.step_observe_device(t.data_ptr(), obs.data_ptr(), obs.numel() * obs.element_size(), auto_reset=bool(auto_reset),
+                                            layout=layout, dtype=np.float32 if tdt == torch.float32 else np.float64)
+        else:
+            self.engine.step_device(t.data_ptr(), auto_reset=auto_reset)
+        obs, done, flag, ill, _ = self._device_results(want_obs, layout=layout, obs_dtype=obs_dtype, obs=obs)
         self.engine.wait()         # (the engine stream only: restarts owed by a deferred auto-reset stay owed)
         return obs, done.bool(), flag, ill
 

@@ -283,6 +283,7 @@ struct DevCase {
   // chronics: slot s occupies rows [c_off[s], c_off[s]+c_T[s]) of every tensor
   int n_slots;
   const float *c_pp, *c_pv, *c_lp, *c_lq, *c_ppp, *c_pvp, *c_lpp, *c_lqp, *c_mt, *c_hz;
+  const int* c_mnext;              // [rows x nl] first row >= this one of the same chronic with a maintenance on the line (chronic-relative index; INT_MAX: none) -- the observation's planned-maintenance field in one load
   const int *c_off, *c_T, *c_next, *c_roll, *c_restart;
   const int* c_roll2;    // [n_slots x n_slots] row loaded first when the chronic `old` rolls over into `new` (quirk q2), any pair
   const int *c_dates;    // [rows x 6]

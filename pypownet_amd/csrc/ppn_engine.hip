@@ -200,12 +200,17 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   for (int env = 0; env < nblocks; ++env) {
     memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));   // LDS is NOT zero-initialised on the GPU either
     if (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_STEP_PERSIST) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0, a.cap_class); }
+    else if (KIND == K_STEP_OBS) {
+      if (a.cap_class >= 0 && (int)a.st.big[env] != a.cap_class) continue;
+      body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, a.restart_prio, env, 0, a.cap_class);
+      if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0);
+    }
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
     else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, 0);
     else if (KIND == K_POLICY) body_policy<W>(a.d, a.st, a.policy, a.policy_out, env, 0);
-    else if (KIND == K_OBS) { if (a.obs_f32) body_obs<float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0); }
+    else if (KIND == K_OBS) { if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0); }
   }
   if (timed) e->launches++;
   return 0;
@@ -258,7 +263,7 @@ static int launch_sched(ppn_engine* e, const KArgs& a, int nblocks) {
 // the others only as NT = 0.
 template <int W, int KIND>
 static int launch_nt(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
-  constexpr bool solves = (KIND == K_STEP || KIND == K_STEP_PERSIST || KIND == K_ROLLOUT || KIND == K_POLICY_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
+  constexpr bool solves = (KIND == K_STEP || KIND == K_STEP_OBS || KIND == K_STEP_PERSIST || KIND == K_ROLLOUT || KIND == K_POLICY_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
   if (solves && e->newton) return launch_w<W, KIND, solves ? 1 : 0>(e, a, nblocks, timed);
   return launch_w<W, KIND, 0>(e, a, nblocks, timed);
 }
@@ -283,7 +288,7 @@ static int set_lds_attr(size_t bytes) {
   int rc = 0;
 #define PPN_ATTR(K, N) rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
   PPN_ATTR(K_STEP, 0) PPN_ATTR(K_STEP, 1) PPN_ATTR(K_GAMEOVER, 0) PPN_ATTR(K_GAMEOVER, 1) PPN_ATTR(K_RESET, 0) PPN_ATTR(K_RESET, 1)
-  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1) PPN_ATTR(K_STEP_PERSIST, 0) PPN_ATTR(K_STEP_PERSIST, 1) PPN_ATTR(K_POLICY_ROLLOUT, 0) PPN_ATTR(K_POLICY_ROLLOUT, 1) PPN_ATTR(K_POLICY, 0)
+  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1) PPN_ATTR(K_STEP_PERSIST, 0) PPN_ATTR(K_STEP_PERSIST, 1) PPN_ATTR(K_POLICY_ROLLOUT, 0) PPN_ATTR(K_POLICY_ROLLOUT, 1) PPN_ATTR(K_POLICY, 0) PPN_ATTR(K_STEP_OBS, 0) PPN_ATTR(K_STEP_OBS, 1)
 #undef PPN_ATTR
   return rc;
 }
@@ -965,6 +970,7 @@ static int sync_chronics(ppn_engine* e) {
   const int ns = (int)e->chronics.size();
   std::vector<int> off(ns), T(ns), next(ns), roll(ns), restart(ns), roll2((size_t)ns * ns), dates;
   std::vector<float> pp, pv, lp, lq, ppp, pvp, lpp, lqp, mt, hz;
+  std::vector<int> mnext;      // per (row, line): the first row >= this one of the SAME chronic with a maintenance on the line (chronic-relative; INT_MAX: none)
   int rows = 0;
   for (int s = 0; s < ns; ++s) {
     const HostChronic& h = e->chronics[s];
@@ -974,6 +980,18 @@ static int sync_chronics(ppn_engine* e) {
     app(pp, h.pp); app(pv, h.pv); app(lp, h.lp); app(lq, h.lq); app(ppp, h.ppp); app(pvp, h.pvp); app(lpp, h.lpp);
     app(lqp, h.lqp); app(mt, h.mt); app(hz, h.hz);
     dates.insert(dates.end(), h.dates.begin(), h.dates.end());
+    {
+      const int nl_ = e->dc.nl;
+      const size_t base = mnext.size();
+      mnext.resize(base + (size_t)h.T * nl_);
+      for (int l = 0; l < nl_; ++l) {
+        int nx = 0x7fffffff;
+        for (int r = h.T - 1; r >= 0; --r) {
+          if (h.mt[(size_t)r * nl_ + l] != 0.0f) nx = r;
+          mnext[base + (size_t)r * nl_ + l] = nx;
+        }
+      }
+    }
   }
   for (int s = 0; s < ns; ++s) {
     // roll-over (game.py:481-493): get_next_chronic() sets the current id to 0, then the NEXT id is looked up in
@@ -1001,6 +1019,7 @@ static int sync_chronics(ppn_engine* e) {
   d.c_ppp = upload(e, ppp, e->chronic_allocs); d.c_pvp = upload(e, pvp, e->chronic_allocs);
   d.c_lpp = upload(e, lpp, e->chronic_allocs); d.c_lqp = upload(e, lqp, e->chronic_allocs);
   d.c_mt = upload(e, mt, e->chronic_allocs); d.c_hz = upload(e, hz, e->chronic_allocs);
+  d.c_mnext = upload(e, mnext, e->chronic_allocs);
   d.c_off = upload(e, off, e->chronic_allocs); d.c_T = upload(e, T, e->chronic_allocs);
   d.c_next = upload(e, next, e->chronic_allocs); d.c_roll = upload(e, roll, e->chronic_allocs);
   d.c_restart = upload(e, restart, e->chronic_allocs); d.c_dates = upload(e, dates, e->chronic_allocs);
@@ -1289,8 +1308,10 @@ extern "C" int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p) {
   return PPN_OK;
 }
 
+static int obs_length(const DevCase& d, int layout);
+struct ObsSpec { void* dst; int sections, stride, f32; };      // ppn_step_observe: where the step kernel writes the observation rows
 static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate, int32_t auto_reset,
-                       int n_steps, int per_step_actions) {
+                       int n_steps, int per_step_actions, const ObsSpec* ob = nullptr) {
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
   const size_t mat = (size_t)e->batch * e->dc.alen;
   const u8* dact = actions;
@@ -1317,6 +1338,7 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
   a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = mode;
   a.n_steps = n_steps; a.action_step_stride = per_step_actions ? mat : 0;
   a.restart_prio = e->restart_prio;
+  if (ob) { a.obs = ob->dst; a.obs_sections = ob->sections; a.obs_stride = ob->stride; a.obs_f32 = ob->f32; }
   int nblocks = e->batch;
   // schedule pre-pass: only where node switches can change the schedule at all (busbars beyond one per substation: the four-word
   // kernels), for the step the launch below executes first
@@ -1340,7 +1362,7 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     const int slots_ = e->persistent ? resident_slots_of(e, lds_step) : 0;
     // (the throughput regime only: see K_STEP_PERSIST; not for the one-word kernels -- an IEEE-14 step is ~40 us, the trip to the
     //  position counter between two of them costs more than the workgroup launch it replaces: 37.9 vs 36.8 M at 16384)
-    const bool pers = e->persistent && e->W >= 2 && n_steps == 1 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)e->batch;
+    const bool pers = !ob && e->persistent && e->W >= 2 && n_steps == 1 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)e->batch;
     hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, pers ? e->d_work : (int*)nullptr, slots_);
     a.perm = e->d_perm;
     if (pers) { a.work_counter = e->d_work; a.n_work = e->batch; nblocks = e->resident_slots; }
@@ -1353,13 +1375,15 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     as.d.ECAP = e->ecap_small; as.d.QCAP = e->ecap_small; as.d.LUCAP = 4 * e->ecap_small;
     as.cap_class = 0;
     e->lds_override = e->lds_small_cap;
-    const int rc_s = as.work_counter ? launch<K_STEP_PERSIST>(e, as, nblocks, true) : launch<K_STEP>(e, as, nblocks, true);
+    const int rc_s = ob ? launch<K_STEP_OBS>(e, as, nblocks, true) : (as.work_counter ? launch<K_STEP_PERSIST>(e, as, nblocks, true) : launch<K_STEP>(e, as, nblocks, true));
     e->lds_override = 0;
     if (rc_s) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
     KArgs al = a;
     al.cap_class = 1; al.perm = nullptr; al.work_counter = nullptr;
-    if (launch<K_STEP>(e, al, e->batch, false)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+    if (ob ? launch<K_STEP_OBS>(e, al, e->batch, false) : launch<K_STEP>(e, al, e->batch, false)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   } else
+  if (ob) { if (launch<K_STEP_OBS>(e, a, nblocks, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err()); }
+  else
   if (n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, true) : (a.work_counter ? launch<K_STEP_PERSIST>(e, a, nblocks, true) : launch<K_STEP>(e, a, nblocks, true))) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   if (a.auto_reset && e->maybe_dead) {
     // environments that were already over when the step began (after ppn_reset or after steps without auto_reset) did
@@ -1378,6 +1402,23 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
   enter(e);
   if (!e || !actions) return PPN_E_INVALID;
   return step_launch(e, actions, actions_on_device, simulate, auto_reset, 1, 0);
+}
+
+extern "C" int ppn_step_observe(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t auto_reset,
+                                int32_t layout, int32_t as_f32, void* obs_device, size_t bytes) {
+  enter(e);
+  if (!e || !actions || !obs_device || layout < 0 || layout > 2) return PPN_E_INVALID;
+  if (auto_reset != 0 && auto_reset != 1) return fail(e, PPN_E_INVALID, "ppn_step_observe: auto_reset must be 0 or 1 (a deferred restart would leave the observation of the ended episode in the rows)");
+  const int len = obs_length(e->dc, layout);
+  const size_t need = (size_t)e->batch * (size_t)len * (as_f32 ? sizeof(float) : sizeof(double));
+  if (bytes < need) return fail(e, PPN_E_INVALID, "ppn_step_observe: buffer too small (%zu < %zu)", bytes, need);
+  if (auto_reset && e->maybe_dead) {      // environments that are over right now are restarted first: their rows then show the restarted episode
+    int rc = ppn_process_game_over(e, nullptr);
+    if (rc) return rc;
+    e->maybe_dead = false;
+  }
+  ObsSpec ob = { obs_device, layout == 0 ? 3 : layout, len, as_f32 ? 1 : 0 };
+  return step_launch(e, actions, actions_on_device, 0, auto_reset, 1, 0, &ob);
 }
 
 extern "C" int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t n_steps,

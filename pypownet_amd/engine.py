@@ -183,6 +183,15 @@ class Engine(object):
         """actions_ptr: device address of a uint8 [batch x action_len] buffer (e.g. torch_tensor.data_ptr())."""
         self._check(self._lib.ppn_step(self._h, C.c_void_p(int(actions_ptr)), 1, 0, int(auto_reset)), 'ppn_step')
 
+    def step_observe_device(self, actions_ptr, obs_ptr, nbytes, auto_reset=True, layout='full', dtype=np.float64):
+        """RunEnv.step as the reference returns it -- the step AND the observation -- in one launch (include/ppn.h,
+        ppn_step_observe): ``actions_ptr`` as for step_device, ``obs_ptr`` the device address of a
+        ``[batch x observation_length(layout)]`` buffer of ``dtype`` (float64 / float32) that every environment's workgroup fills
+        right behind its step.  Same rows as ``step_device`` + ``observations_into_device``."""
+        self._check(self._lib.ppn_step_observe(self._h, C.c_void_p(int(actions_ptr)), 1, int(bool(auto_reset)), self.OBS_LAYOUTS[layout],
+                                               1 if np.dtype(dtype) == np.float32 else 0, C.c_void_p(int(obs_ptr)), int(nbytes)),
+                    'ppn_step_observe')
+
     def rollout(self, actions, n_steps=None, auto_reset=True):
         """Open-loop rollout (include/ppn.h, ppn_rollout): ``actions`` is ``[n_steps x batch x action_length]`` (one matrix per
         step) or ``[batch x action_length]`` replayed ``n_steps`` times (the do-nothing agent); one launch, every environment

@@ -1166,3 +1166,60 @@ def check_two_capacity_stepping(lib_path, steps=16, batch=12, solver='newton', s
         assert int((a.read('FLAG') == 4).sum()) == 0
     a.close(); b.close()
     return dict(big=n_big, small=n_small)
+
+
+def check_step_observe(lib_path, envname='default14', batch=6, n_steps=12, solver='newton', layout='full', dtype=np.float64, seed=5,
+                       auto_reset=True, **engine_kw):
+    """ppn_step_observe (the step and the observation rows in one launch) against ppn_step followed by ppn_read_observation: the rows,
+    and every state / report field, bit for bit the same -- under random node-splitting / line-switching actions, with episodes that
+    end (and, auto_reset = 1, restart) on the way."""
+    case, cfg, chronics = load_env(envname, conf={'solver': solver})
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)      # two calls
+    b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)      # one launch
+    for e in (a, b):
+        e.reset()
+    n = a.observation_length(layout)
+    item = np.dtype(dtype).itemsize
+    rng = np.random.default_rng(seed)
+    gpu = lib_path is None
+    if gpu:
+        import torch
+        tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        act_d = torch.zeros((batch, case.action_length), dtype=torch.uint8, device='cuda')
+        oa, ob = (torch.full((batch, n), -7.0, dtype=tdt, device='cuda') for _ in range(2))
+        torch.cuda.synchronize()
+    else:
+        act_h = np.zeros((batch, case.action_length), dtype=np.uint8)
+        oa, ob = (np.full((batch, n), -7.0, dtype=dtype) for _ in range(2))
+    ended = 0
+    for t in range(n_steps):
+        acts = np.zeros((batch, case.action_length), dtype=np.uint8)
+        for k in range(batch):
+            if rng.random() < 0.6:
+                sub = int(rng.integers(case.nS))
+                idx = np.asarray(case.mapping_array[sub], dtype=int)
+                acts[k, idx] = rng.integers(0, 2, size=len(idx))
+            if rng.random() < 0.3:
+                acts[k, case.n_topo + int(rng.integers(case.nl))] = 1
+        if gpu:
+            act_d.copy_(torch.from_numpy(acts)); torch.cuda.synchronize()
+            ap, pa, pb = act_d.data_ptr(), oa.data_ptr(), ob.data_ptr()
+        else:
+            act_h[:] = acts
+            ap, pa, pb = act_h.ctypes.data, oa.ctypes.data, ob.ctypes.data
+        a.step_device(ap, auto_reset=auto_reset)
+        a.observations_into_device(pa, batch * n * item, layout=layout, dtype=dtype)
+        b.step_observe_device(ap, pb, batch * n * item, auto_reset=auto_reset, layout=layout, dtype=dtype)
+        a.sync(); b.sync()
+        ha, hb = (oa.cpu().numpy(), ob.cpu().numpy()) if gpu else (oa, ob)
+        assert np.array_equal(ha, hb, equal_nan=True), (t, np.argwhere(ha != hb)[:5])
+        assert not (hb == -7.0).all(axis=1).any()          # every row was written
+        for f in ('VM', 'VA', 'PF', 'AMPS', 'PG', 'QG', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'CHRONIC_ROW',
+                  'CHRONIC_SLOT', 'N_SOLVES', 'N_ITERS', 'DONE', 'FLAG', 'ILLEGAL', 'REWARD', 'CASCADE_DEPTH', 'EPOCH', 'DEAD'):
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
+        ended += int(a.read('DONE').sum())
+        if not auto_reset and a.read('DEAD').any():
+            for e in (a, b):
+                e.process_game_over()
+    a.close(); b.close()
+    return ended

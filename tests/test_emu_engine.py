@@ -219,3 +219,22 @@ def test_emu_two_capacity_stepping(emu_lib, small_ecap, auto_reset):
 def test_emu_two_capacity_stepping_fast_decoupled(emu_lib):
     st = ec.check_two_capacity_stepping(emu_lib, steps=14, batch=8, small_ecap=660, auto_reset=True, solver='fdxb')
     assert st['small'] > 0 and st['big'] > 0, st
+
+
+@pytest.mark.parametrize('envname,solver,layout,dtype,auto_reset', [
+    ('default14', 'newton', 'full', 'float64', True), ('default14', 'fdxb', 'minimalist', 'float32', True),
+    ('default14_for_tests_alpha', 'newton', 'ac_minimalist', 'float64', False), ('default30', 'dc', 'full', 'float32', True)])
+def test_emu_step_observe_equals_step_then_read(emu_lib, envname, solver, layout, dtype, auto_reset):
+    import numpy as np
+    ended = ec.check_step_observe(emu_lib, envname, 5, 14, solver, layout, np.dtype(dtype), auto_reset=auto_reset)
+    assert ended > 0 or envname != 'default14'
+
+
+def test_emu_step_observe_two_capacity_118(emu_lib):
+    """Four-word kernels with two-capacity stepping (both class launches write their environments' rows)."""
+    import os
+    os.environ['PPN_TWO_CAP_ECAP'] = '760'
+    try:
+        ec.check_step_observe(emu_lib, 'default118', 4, 4, 'newton', 'full')
+    finally:
+        del os.environ['PPN_TWO_CAP_ECAP']

@@ -569,3 +569,26 @@ def test_gpu_two_capacity_stepping_fast_decoupled():
     assert st['small'] > 0 and st['big'] > 0, st
     st = ec.check_two_capacity_stepping(HIP, steps=12, batch=1024, small_ecap=0, auto_reset=2, solver='fdxb')
     assert st['small'] > 0, st
+
+
+@pytest.mark.parametrize('envname,solver,layout,dtype,auto_reset,batch', [
+    ('default14', 'newton', 'full', 'float64', True, 64), ('default14', 'fdxb', 'minimalist', 'float32', True, 64),
+    ('default14_for_tests_alpha', 'newton', 'ac_minimalist', 'float64', False, 16), ('default30', 'dc', 'full', 'float32', True, 32),
+    ('default118', 'newton', 'full', 'float64', True, 48)])
+def test_gpu_step_observe_equals_step_then_read(envname, solver, layout, dtype, auto_reset, batch):
+    """ppn_step_observe: the observation rows written by the step kernel's workgroups = ppn_step + ppn_read_observation, bit for bit."""
+    import numpy as np
+    ec.check_step_observe(HIP, envname, batch, 14, solver, layout, np.dtype(dtype), auto_reset=auto_reset)
+
+
+def test_gpu_step_observe_bench_workload_2048():
+    """... and on the bench workload (two-word kernels, launch order on: 2048 environments, cascade limits, do-nothing + switches)."""
+    import json
+    import os
+    import numpy as np
+    from helpers import ENVS
+    with open(os.path.join(ENVS, 'default118', 'bench_limits.json')) as f:
+        lim = np.asarray(json.load(f)['limits_a'])
+    from helpers import load_env
+    case, _, _ = load_env('default118')
+    ec.check_step_observe(HIP, 'default118', 2048, 6, 'newton', 'full', np.float64, thermal_limits=lim, max_active_buses=case.nS)
