@@ -1391,6 +1391,9 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     // kernel, so from the second auto-reset step on nothing is left to do here.
     if (launch<K_GAMEOVER>(e, a, e->batch)) return fail(e, PPN_E_HIP, "game-over kernel launch failed: %s", dev_err());
     e->maybe_dead = false;
+    // (ppn_step_observe: the rows of the environments this post-pass restarted were written before it -- gathered once more; only
+    //  the first auto-reset step after a ppn_reset or after steps without auto_reset comes through here)
+    if (ob && launch<K_OBS>(e, a, e->batch)) return fail(e, PPN_E_HIP, "observation kernel launch failed: %s", dev_err());
   }
   if (!a.auto_reset && !simulate) e->maybe_dead = true;
   if (mode == 2) e->pending_restart = true;
@@ -1412,11 +1415,6 @@ extern "C" int ppn_step_observe(ppn_engine* e, const uint8_t* actions, int32_t a
   const int len = obs_length(e->dc, layout);
   const size_t need = (size_t)e->batch * (size_t)len * (as_f32 ? sizeof(float) : sizeof(double));
   if (bytes < need) return fail(e, PPN_E_INVALID, "ppn_step_observe: buffer too small (%zu < %zu)", bytes, need);
-  if (auto_reset && e->maybe_dead) {      // environments that are over right now are restarted first: their rows then show the restarted episode
-    int rc = ppn_process_game_over(e, nullptr);
-    if (rc) return rc;
-    e->maybe_dead = false;
-  }
   ObsSpec ob = { obs_device, layout == 0 ? 3 : layout, len, as_f32 ? 1 : 0 };
   return step_launch(e, actions, actions_on_device, 0, auto_reset, 1, 0, &ob);
 }

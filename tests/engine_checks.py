@@ -1176,8 +1176,10 @@ def check_step_observe(lib_path, envname='default14', batch=6, n_steps=12, solve
     case, cfg, chronics = load_env(envname, conf={'solver': solver})
     a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)      # two calls
     b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **engine_kw)      # one launch
+    from pypownet_amd.batched import default_assignment
+    slots, t0 = default_assignment(np.arange(batch) * 7, chronics)      # (start rows all over the chronics: some environments are over right after the reset)
     for e in (a, b):
-        e.reset()
+        e.reset(chronic_slot=slots, t0=t0)
     n = a.observation_length(layout)
     item = np.dtype(dtype).itemsize
     rng = np.random.default_rng(seed)
