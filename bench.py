@@ -80,8 +80,19 @@ def pmc_summary(batch):
 
 
 def measured_traffic(batch):
+    """(bytes per launch or None, where it comes from / why it is missing)."""
     p = pmc_summary(batch)
-    return float(p['hbm_bytes_per_launch']) if p else None
+    if not p:
+        return None, None
+    want = p.get('library_sha256')
+    try:
+        have = library_sha256()
+    except OSError:
+        have = None
+    if want is None or want != have:
+        return None, 'dropped: %s was collected on another build (summary %s, this library %s)' % (
+            p['file'], (want or 'unstamped')[:12], (have or '?')[:12])
+    return float(p['hbm_bytes_per_launch']), p['file']
 
 
 def env_assignment(first, count, chronics):
@@ -93,53 +104,64 @@ def env_assignment(first, count, chronics):
 
 
 def cpu_baseline(case, conf, chronics, limits, budget_s=12.0):
-    """C oracle (oracle/ppn_oracle.c, OpenMP over environments) on a bounded sample of the same workload."""
+    """The reference's CPU path, timed beside the GPU figure on this box's host cores (SURVEY.md 8d (i)).
+
+    `value` = the REFERENCE-EQUIVALENT PYTHON BACKEND: oracle/game_np.py -- the numpy / scipy restatement of pypownet's Grid + Game
+    over PYPOWER's algorithm (scipy.sparse + SuperLU, the library class the reference itself runs; PYPOWER is not installed here) --
+    one environment on one host core, the same workload.  That is what the reference is: one Python process per environment
+    (README.md:9 quotes ~25 steps/s on default14).
+    `checker_port_*` = the C checker (oracle/ppn_oracle.c, OpenMP over environments, every host thread): reported because it is the
+    fastest CPU code in this repository, NOT as "the CPU" -- it redoes the symbolic factorisation in every solve and was written to
+    be compared against, not to be fast (VERDICT r05 #8); a KLU-class refactorising solver would be several times faster."""
     import subprocess
     from harness import oracle_engine            # tests/harness.py: the checker library is driven from outside the product
-    lib = os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')
-    if not os.path.exists(lib):
-        try:
-            subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
-        except Exception:
-            return None
-    cores = os.cpu_count() or 1
-    nb = max(256, 16 * cores)
-    eng = oracle_engine(case, conf, nb, chronics=chronics, thermal_limits=limits)
-    threads = max(1, eng.dim(12))
-    slots, t0 = env_assignment(0, nb, chronics)
-    eng.reset(chronic_slot=slots, t0=t0)
-    act = np.zeros((nb, case.action_length), dtype=np.uint8)
-    eng.step(act, auto_reset=True)
-    t = time.perf_counter()
-    steps = 0
-    while True:
-        eng.step(act, auto_reset=True)
-        steps += 1
-        el = time.perf_counter() - t
-        if el > budget_s or steps >= 4000:
-            break
-    out = {'value': nb * steps / el, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-           'sample': '%d envs x %d steps of the same workload (%.1f s), C oracle, OpenMP over envs' % (nb, steps, el),
-           'note': 'unoptimised checker port (symbolic work redone per solve): the GPU/CPU ratio is not a quality measure'}
-    # SURVEY.md 8d (i): the "reference-equivalent Python backend" -- the numpy/scipy restatement of the PYPOWER path
-    # (scipy.sparse + SuperLU, the library class the reference uses), one environment on one host core, same workload
+    out = {'value': None, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port', 'sample': None}
     try:
         from oracle.game_np import OracleGame
         g = OracleGame(case, conf, chronics, thermal_limits=limits)
         a1 = np.zeros(case.action_length, dtype=np.int64)
         t = time.perf_counter()
         n1 = 0
-        while time.perf_counter() - t < 4.0:
+        while time.perf_counter() - t < budget_s:
             if g.step(a1)[3]:
                 g.process_game_over()
             n1 += 1
-        # (flat keys: a nested dict did not survive the driver's parser in round 3)
-        out['python_restatement_value'] = n1 / (time.perf_counter() - t)
+        el1 = time.perf_counter() - t
+        out['value'] = n1 / el1
+        out['sample'] = ('1 env x %d steps of the same workload (%.1f s), oracle/game_np.py: numpy + scipy SuperLU restatement of the '
+                         'reference Python backend, 1 core' % (n1, el1))
+        # (the keys round 4/5 lines carried, kept for comparisons across rounds)
+        out['python_restatement_value'] = out['value']
         out['python_restatement_cores'] = 1
-        out['python_restatement_sample'] = '1 env x %d steps, oracle/game_np.py (numpy + scipy SuperLU), env-steps/s' % n1
     except Exception as ex:
-        out['python_restatement_value'] = None
-        out['python_restatement_sample'] = 'failed: %s' % ex
+        out['sample'] = 'python restatement failed: %s' % ex
+    try:
+        lib = os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')
+        if not os.path.exists(lib):
+            subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
+        cores = os.cpu_count() or 1
+        nb = max(256, 16 * cores)
+        eng = oracle_engine(case, conf, nb, chronics=chronics, thermal_limits=limits)
+        threads = max(1, eng.dim(12))
+        slots, t0 = env_assignment(0, nb, chronics)
+        eng.reset(chronic_slot=slots, t0=t0)
+        act = np.zeros((nb, case.action_length), dtype=np.uint8)
+        eng.step(act, auto_reset=True)
+        t = time.perf_counter()
+        steps = 0
+        while True:
+            eng.step(act, auto_reset=True)
+            steps += 1
+            el = time.perf_counter() - t
+            if el > budget_s or steps >= 4000:
+                break
+        out['checker_port_value'] = nb * steps / el
+        out['checker_port_cores'] = threads
+        out['checker_port_sample'] = '%d envs x %d steps (%.1f s), C checker oracle/ppn_oracle.c, OpenMP over envs' % (nb, steps, el)
+        out['checker_port_note'] = 'unoptimised checker (symbolic work redone per solve): not a tuned CPU solver'
+    except Exception as ex:
+        out['checker_port_value'] = None
+        out['checker_port_sample'] = 'failed: %s' % ex
     return out
 
 
@@ -181,6 +203,32 @@ def random_node_splitting(case, rng, batch):
     return acts
 
 
+def philox_node_splitting(case, env_ids, k, seed=1234):
+    """per environment and step a RandomNodeSplitting-style action (reference pypownet/agent.py:116-158) drawn
+    from a counter-based generator philox(seed, env, step) -- substation ~ U{nS}, configuration ~ Bernoulli(0.5)^k_s.  A function of
+    the GLOBAL environment id and the step alone: however the batch is sharded over ranks, environment g plays the same actions."""
+    acts = np.zeros((len(env_ids), case.action_length), dtype=np.uint8)
+    for b, g in enumerate(env_ids):
+        rng = np.random.Generator(np.random.Philox(key=seed, counter=[int(k), int(g), 0, 0]))
+        idx = np.asarray(case.mapping_array[int(rng.integers(case.nS))], dtype=int)
+        acts[b, idx] = rng.integers(0, 2, size=len(idx))
+    return acts
+
+
+SPLIT_ACTION_MATRICES = 8      # the split workload cycles through this many pre-drawn action matrices (step s plays matrix s mod 8)
+
+
+def library_sha256():
+    """Hash of the library this process loads (pypownet_amd/libppn.so): stamped into profiles/r*_pmc_summary.json by
+    tools/summarize_pmc.py, so that a PMC pass of ANOTHER build is not reported as this build's traffic (VERDICT r05 #7a)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(os.path.join(ROOT, 'pypownet_amd', 'libppn.so'), 'rb') as f:
+        for blk in iter(lambda: f.read(1 << 20), b''):
+            h.update(blk)
+    return h.hexdigest()
+
+
 def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=None, split=False, max_active=None, warmup=4,
                 histogram=False, lu_capacity=0, watch_capacity=0, q_plane_auto=0):
     """One of the other single-GPU configurations of BASELINE.json, timed like the headline (device-resident actions, K steps
@@ -198,10 +246,9 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
     eng = Engine(case, conf, batch, device=device, chronics=chronics, thermal_limits=limits, **kw)
     slots, t0 = env_assignment(0, batch, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
-    rng = np.random.default_rng(1234)
-    n_act = 8 if split else 1
-    acts = [torch.from_numpy(random_node_splitting(case, rng, batch) if split else
-                             np.zeros((batch, case.action_length), dtype=np.uint8)).to('cuda:%d' % device) for _ in range(n_act)]
+    n_act = SPLIT_ACTION_MATRICES if split else 1
+    acts = [torch.from_numpy(philox_node_splitting(case, np.arange(batch), k) if split else
+                             np.zeros((batch, case.action_length), dtype=np.uint8)).to('cuda:%d' % device) for k in range(n_act)]
     torch.cuda.synchronize()
     for k in range(warmup):
         eng.step_device(acts[k % n_act].data_ptr(), auto_reset=auto_reset)
@@ -346,6 +393,10 @@ def main():
     ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
+    ap.add_argument('--workload', choices=['cascade', 'split'], default='cascade',
+                    help="cascade: BASELINE.json configs[2]/[3], do-nothing agent, cascade limits (the headline).  split: configs[4], "
+                         'per-environment random node-splitting actions every step (philox(1234, env, step)), every busbar may be '
+                         'active (four-word kernels, default capacities: two-capacity stepping) -- runs under --gpus N like the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the side measurements of the other single-GPU configurations')
     ap.add_argument('--no-rollout', action='store_true',
@@ -410,25 +461,46 @@ def main():
     # engine brackets every 4th launch of the timed region only (every launch when K is small); `value` is wall-clock over all K
     timing_every = int(os.environ.get('PPN_KERNEL_TIMING_EVERY', '4' if args.steps >= 16 else '1'))
     os.environ['PPN_KERNEL_TIMING_EVERY'] = str(timing_every)
-    eng = Engine(case, conf, B, device=local_rank, chronics=chronics, thermal_limits=limits, max_active_buses=case.nS,
-                 lu_capacity=int(os.environ.get('PPN_BENCH_LU_CAPACITY', '0')))   # (occupancy experiments only)
+    SPLIT = args.workload == 'split'
+    if SPLIT:      # configs[4]: node switches every step -- every busbar may be active, the engine's default capacities
+        eng = Engine(case, conf, B, device=local_rank, chronics=chronics, thermal_limits=limits,
+                     lu_capacity=int(os.environ.get('PPN_BENCH_LU_CAPACITY', '0')), q_plane_auto=int(os.environ.get('PPN_BENCH_Q_PLANE_AUTO', '0')))
+    else:
+        eng = Engine(case, conf, B, device=local_rank, chronics=chronics, thermal_limits=limits, max_active_buses=case.nS,
+                     lu_capacity=int(os.environ.get('PPN_BENCH_LU_CAPACITY', '0')))   # (occupancy experiments only)
     slots, t0 = env_assignment(rank * B, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
     import zlib
-    crcs = [zlib.crc32(slots.tobytes() + t0.tobytes())]      # which environments this rank plays (checked by the 2-rank test)
+    my_crc = zlib.crc32(slots.tobytes() + t0.tobytes())      # which environments this rank plays (checked by the 2-rank test)
+    dev_name = 'cuda:%d' % local_rank
+    if SPLIT:
+        host_acts = [philox_node_splitting(case, np.arange(rank * B, (rank + 1) * B), k) for k in range(SPLIT_ACTION_MATRICES)]
+        for h_ in host_acts:
+            my_crc = zlib.crc32(h_.tobytes(), my_crc)         # ... and which actions they play
+        act_list = [torch.from_numpy(h_).to(dev_name) for h_ in host_acts]
+    else:
+        act_list = [torch.zeros((B, case.action_length), dtype=torch.uint8, device=dev_name)]
+    crcs = [my_crc]
     if use_dist:
         crcs = [None] * world
-        dist.all_gather_object(crcs, zlib.crc32(slots.tobytes() + t0.tobytes()))
-    actions = torch.zeros((B, case.action_length), dtype=torch.uint8, device='cuda:%d' % local_rank)
+        dist.all_gather_object(crcs, my_crc)
+    actions = act_list[0]
     torch.cuda.synchronize()
     aptr = actions.data_ptr()
+    aptrs = [a_.data_ptr() for a_ in act_list]
+    step_no = [0]
+
+    def next_actions():      # (the action matrix of the next step: the same for every step of the do-nothing workload)
+        k_ = step_no[0] % len(aptrs)
+        step_no[0] += 1
+        return k_
 
     # auto_reset = 2 (include/ppn.h, ppn_step): an episode that ends is restarted at the head of the environment's NEXT step
     # launch instead of at the tail of this one; eng.sync() settles the restarts still owed, so that every restart of the K
     # timed steps is inside the timed region
     AUTO_RESET = int(os.environ.get('PPN_BENCH_AUTO_RESET', '2'))
     for _ in range(args.warmup):
-        eng.step_device(aptr, auto_reset=AUTO_RESET)
+        eng.step_device(aptrs[next_actions()], auto_reset=AUTO_RESET)
     eng.sync()
     exchange = None
     if args.single_controller and use_dist:
@@ -451,7 +523,10 @@ def main():
         # the gather runs on a communicator and a stream of its own: the scatter of step t + 1 (default group, scatter stream) and
         # step t + 1 itself then do not queue behind the gather of step t -- what a controller whose policy does not need step t's
         # report to choose the actions of step t + 1 (the do-nothing controller of this bench) can overlap
-        g_gather = dist.new_group(backend=backend) if not on_host else None
+        # (RCCL documents collectives issued concurrently on TWO communicators as deadlock-prone when their device-side
+        #  order differs across ranks -- the second communicator is only used on a world of ONE rank, where there is no other rank
+        #  to disagree with; with more ranks both collectives go through the default communicator, in program order on every rank)
+        g_gather = dist.new_group(backend=backend) if (not on_host and world == 1) else None
         s_scatter, s_gather = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if not on_host else (None, None)
 
         def exchange():
@@ -496,12 +571,13 @@ def main():
         if exchange is not None:
             exchange()
         else:
-            eng.step_device(aptr, auto_reset=AUTO_RESET)
+            eng.step_device(aptrs[next_actions()], auto_reset=AUTO_RESET)
     eng.sync()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    step_form = eng.last_step_form()
 
     kms, klaunch = eng.kernel_time(reset=True)
     ns1, ni1 = eng.read('N_SOLVES').astype(np.int64).sum(), eng.read('N_ITERS').astype(np.int64).sum()
@@ -509,6 +585,33 @@ def main():
     depth_now = float(eng.read('CASCADE_DEPTH').mean())
     executed = float(eng.read('N_STEPS').astype(np.int64).sum() - nst0)      # Game.step calls executed by this rank (PPN_F_N_STEPS)
     dead_now = float((eng.read('DEAD') != 0).sum())
+    # the same loop once more over 60 steps (VERDICT r05 #7c: at the driver's K = 20 the timed region is 6.5 ms and the last digits of
+    # `value` are noise): `value_k60`, reported beside `value`, never instead of it -- 20 ms of GPU time
+    K60 = 60
+    value_k60 = None
+    if exchange is None and args.steps < K60 and not args.headline_only:
+        e0 = float(eng.read('N_STEPS').astype(np.int64).sum())
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t60 = time.perf_counter()
+        for _ in range(K60):
+            eng.step_device(aptrs[next_actions()], auto_reset=AUTO_RESET)
+        eng.sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el60 = time.perf_counter() - t60
+        st60 = torch.tensor([el60, float(eng.read('N_STEPS').astype(np.int64).sum()) - e0], dtype=torch.float64,
+                            device=dev_name if backend == 'nccl' else 'cpu')
+        if use_dist:
+            mx60, sm60 = st60.clone(), st60.clone()
+            dist.all_reduce(mx60, op=dist.ReduceOp.MAX)
+            dist.all_reduce(sm60, op=dist.ReduceOp.SUM)
+            value_k60 = float(sm60[1]) / float(mx60[0])
+        else:
+            value_k60 = float(st60[1]) / float(st60[0])
+        eng.kernel_time(reset=True)
     stats = torch.tensor([elapsed, float(ns1 - ns0), float(ni1 - ni0), kms, float(klaunch), executed, dead_now], dtype=torch.float64,
                          device=('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu')
     if use_dist:
@@ -531,11 +634,12 @@ def main():
         avg_kernel_s = (kms / 1e3) / max(klaunch, 1)                          # rank 0's step kernel, HIP events
         per_launch = executed / float(args.steps)                              # env-steps rank 0's kernel executes per launch
         achieved = per_launch * b_step / avg_kernel_s / 1e9 if avg_kernel_s > 0 else None
-        pmc = pmc_summary(B)
+        pmc = pmc_summary(B) if not SPLIT else None
+        traffic, traffic_src = measured_traffic(B) if not SPLIT else (None, None)
         flop_step = solves_per_step * iters_per_solve * FLOP_PER_NR_ITERATION
         tflops = per_launch * flop_step / avg_kernel_s / 1e12 if avg_kernel_s > 0 else None
         sq = (pmc or {}).get('sq_shares_of_wave_cycles') or {}
-        persistent_form = B >= 4 * 1792          # (ppn_engine.hip: the persistent form of the step kernel from 4 environments per resident slot on)
+        form_name, two_cap_form = step_form      # (what the engine launched: ppn_dim(19))
         # NOTE on the shape of this line: the driver's parser keeps scalars one level deep and cuts strings at ~130 characters
         # (round 4: nested dicts, lists and the long `other_configs` entries were dropped) -- everything below is flat and short;
         # the long form of the side measurements goes to PPN_BENCH_DETAILS (default gpurun_out/bench_details.json when that
@@ -544,6 +648,7 @@ def main():
             'metric': 'env steps/sec, batched IEEE-118 AC load-flow',
             'value': total_steps / elapsed,
             'unit': 'env-steps/s',
+            'value_k60': value_k60,      # the same loop over 60 steps in the same run (None when --steps >= 60: `value` is that)
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
@@ -553,7 +658,10 @@ def main():
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic: IEEE-118 case + reference chronic series (fixture), synthetic thermal limits',
-            'config': {'workload': 'default118 AC Newton (tol 1e-6), %d envs/GPU, cascade loop, do-nothing agent, auto reset' % B,
+            'config': {'workload': ('default118 AC Newton (tol 1e-6), %d envs/GPU, cascade loop, per-env random node splitting every step '
+                                    '(philox(1234, env, step)), every busbar may be active, auto reset' if SPLIT else
+                                    'default118 AC Newton (tol 1e-6), %d envs/GPU, cascade loop, do-nothing agent, auto reset') % B,
+                       'workload_name': args.workload,
                        'batch_per_gpu': B, 'solver': 'newton',
                        'parallelism': ('env-sharded x%d, single controller: RCCL scatter actions + gather report per step' if exchange is not None else
                                        'env-sharded x%d, no collective in the step loop') % world,
@@ -565,11 +673,12 @@ def main():
                        'single_controller': exchange is not None, 'dist_backend': (backend if use_dist else None),
                        'mean_cascade_depth_last_step': depth_now},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': measured_traffic(B),
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
                          # `traffic` is NOT measured in this run (counters cannot be collected from inside the timed run): it is the
                          # rocprofv3 PMC pass of this build committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE per launch)
-                         'traffic_source': (pmc or {}).get('file'),
-                         'kernel': 'ppn_kernel<W=2,%s,NT=1>' % ('K_STEP_PERSIST' if persistent_form else 'K_STEP'),
+                         'traffic_source': traffic_src,
+                         'kernel': 'ppn_kernel<W=%d,%s,NT=1>%s' % (4 if SPLIT else 2, form_name,
+                                                                   ' x 2 capacity classes + schedule pre-pass (one event bracket)' if two_cap_form else ''),
                          'avg_kernel_ms': 1e3 * avg_kernel_s,
                          'kernel_timing': 'HIP events on the engine stream, every %d%s step launch: %d launches' % (
                              timing_every, 'th' if timing_every > 1 else 'st', int(klaunch)),
@@ -587,7 +696,7 @@ def main():
             'cpu_baseline': None,
         }
         details = {}
-        if world == 1 and not args.no_rollout:
+        if world == 1 and not SPLIT and not args.no_rollout:
             # OPEN-LOOP rollout (ppn_rollout): the same K steps of the same do-nothing agent in ONE launch -- every environment
             # plays its K steps back to back instead of waiting, after every step, for the longest cascade of the batch.  Same
             # results bit for bit (tests: check_rollout_equals_steps); only usable when the actions do not depend on the
@@ -601,7 +710,7 @@ def main():
             el_r = time.perf_counter() - t_r
             r1 = int(eng.read('N_STEPS').astype(np.int64).sum())
             out['config']['open_loop_rollout_env_steps_per_s'] = (r1 - r0) / el_r      # (ppn_rollout, open-loop agents only; not the headline)
-        if world == 1 and exchange is None and not args.headline_only:
+        if world == 1 and not SPLIT and exchange is None and not args.headline_only:
             # CLOSED LOOP WITH THE OBSERVATION (what RunEnv.step returns, environment.py:848-866): the same step followed by the
             # observation gather (K_OBS) into a device tensor, every step -- what a policy that lives on this GPU pays.  Full
             # Observation.as_array() in float64 (4 967 values = 39.7 KB per environment) and the minimalist layout in float32.
@@ -647,7 +756,7 @@ def main():
                 eng.sync()
                 out['config'][key] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - c0) / (time.perf_counter() - t_o)
                 del obs_t
-        if world == 1 and exchange is None and not args.no_rollout:
+        if world == 1 and not SPLIT and exchange is None and not args.no_rollout:
             # CLOSED LOOP WITHOUT THE BATCH BARRIER (ppn_rollout_policy, round 5): a policy that lives on the device -- the built-in
             # toy operator: reconnect a reconnectable line, else open the most loaded line beyond its limit -- and every environment
             # on its own clock: work items (step, environment) go to whichever workgroup is free, trajectories bit for bit those of
@@ -673,7 +782,7 @@ def main():
             eng.rollout_policy('line_relief', [1.0], args.steps)
             eng.sync()
             out['config']['closed_loop_device_policy_rollout_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - p0) / (time.perf_counter() - t_p)
-        if world == 1 and not args.headline_only:
+        if world == 1 and not SPLIT and not args.headline_only:
             # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
             # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`
             host_actions = np.zeros((B, case.action_length), dtype=np.uint8)
@@ -685,7 +794,7 @@ def main():
                 eng.read('DONE'); eng.read('FLAG'); eng.read('REWARD')
             eng.sync()
             out['config']['host_boundary_env_steps_per_s'] = B * n_host / (time.perf_counter() - t_h)
-        if world == 1 and not args.no_other_configs and B == BATCH_PER_GPU and exchange is None:
+        if world == 1 and not SPLIT and not args.no_other_configs and B == BATCH_PER_GPU and exchange is None:
             eng.close()
             long_form = other_configs(local_rank, AUTO_RESET, max(12, min(40, args.steps)))
             details['other_configs'] = long_form

@@ -372,7 +372,8 @@ int ppn_sync(ppn_engine* e);        /* settles the restarts a deferred auto-rese
 int ppn_wait(ppn_engine* e);        /* waits for the engine's stream only */
 /* HIP stream the engine launches on (void* = hipStream_t), for callers that time with HIP events. */
 void* ppn_stream(ppn_engine* e);
-/* Average / last device time of the dominant kernel measured with HIP events on the engine stream. */
+/* Average / last device time of the dominant kernel measured with HIP events on the engine stream.  Under two-capacity stepping
+ * one "launch" is the whole step: schedule pre-pass + launch order + small-storage launch + large-storage launch, one bracket. */
 int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, int64_t* launches);
 
 /* ---- introspection --------------------------------------------------------------------------------- */
@@ -384,7 +385,10 @@ int32_t ppn_dim(const ppn_engine* e, int32_t which);   /* 0 nS, 1 nP, 2 nL, 3 nl
                                                           capacity of the Newton storage, 16 environments resident per CU
                                                           (hipOccupancyMaxActiveBlocksPerMultiprocessor of the step kernel),
                                                           17 / 18 two-capacity stepping: pattern capacity and LDS bytes of the
-                                                          small-storage launch (0: off -- see rules.lu_capacity) */
+                                                          small-storage launch (0: off -- see rules.lu_capacity),
+                                                          19 kernel form the LAST step launch took: 0 one workgroup per environment
+                                                          (K_STEP), 1 persistent (K_STEP_PERSIST), 2 step + observation (K_STEP_OBS),
+                                                          3 rollout; + 4 when it was stepped in two capacity classes */
 const char* ppn_version(void);
 
 #ifdef __cplusplus

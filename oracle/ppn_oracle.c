@@ -72,6 +72,7 @@ typedef struct {
   int id, src;      /* index of the environment (seed of its chronic draws), outcome of the last solve of the step's cascade */
   unsigned draws;   /* chronics drawn so far (PPN_LOOP_RANDOM) */
   int done, dead, succ, flag, ill, depth, nsolve, niter, slot, row, nlc, npc, epoch;
+  int nstep;            /* Game.step calls executed since orc_reset (PPN_F_N_STEPS) */
   int illn[3], actsw[2];   /* IllegalActionException contents as counts; node / line switches of the action after the step */
   double min_vm;    /* test diagnostic: smallest |V| of an active bus over the solves of the last step (the last
                        iterate of a failed one included: a solve that reaches V = 0 exactly fails on the NaN it produces) */
@@ -675,6 +676,7 @@ static void orc_step_env(const OCase* c, OEnv* e, const uint8_t* action, int sim
   int flag = flag_of(rc);
   if (!flag) flag = orc_cut_flags(c, e);
   e->flag = flag; e->ill = ill; e->done = flag != 0; e->dead = flag != 0;
+  if (!sim) e->nstep++;
 }
 
 static void orc_game_over_env(const OCase* c, OEnv* e, int force) {
@@ -693,7 +695,9 @@ static void orc_game_over_env(const OCase* c, OEnv* e, int force) {
     if (rc == 0 || rc == 4) break;
   }
   orc_cut_flags(c, e);
-  e->dead = rc != 0;
+  /* dead = 3: 64 restarts in a row diverged as well (the engine's PPN_RESTART_ATTEMPTS, include/ppn.h -- the reference recurses
+   * without a bound, game.py:776-780): the environment stays over and the next pass goes on trying */
+  e->dead = rc == 0 ? 0 : (rc == 4 ? 1 : 3);
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -821,7 +825,7 @@ int orc_reset(orc_engine* E, const int32_t* env_ids, int32_t n, const int32_t* s
     orc_reset_grid(c, e);
     for (int l = 0; l < c->nl; ++l) { e->soft[l] = 0; e->amps[l] = 0; }
     for (int g = 0; g < c->nP; ++g) { e->pg[g] = 0; e->qg[g] = c->qg0[g]; e->vg[g] = 0; }
-    e->slot = slots ? slots[k] : 0; e->row = (t0 ? t0[k] : 0) - 1; e->epoch = 1; e->nsolve = 0; e->niter = 0;
+    e->slot = slots ? slots[k] : 0; e->row = (t0 ? t0[k] : 0) - 1; e->epoch = 1; e->nsolve = 0; e->niter = 0; e->nstep = 0;
     memset(e->lev, 0, c->nl);
     orc_advance(c, e, 0, 1);
     const int rc = orc_cascade(c, e, 1);
@@ -838,8 +842,13 @@ int orc_step(orc_engine* E, const uint8_t* actions, int32_t on_device, int32_t s
   for (int b = 0; b < E->batch; ++b) {
     OEnv* e = &E->env[b];
     if (simulate) { env_copy(c, &E->sim[b], e); e = &E->sim[b]; }
+    /* a restart that ran out of attempts is taken up again BEFORE the step of the next auto-reset launch (include/ppn.h,
+     * ppn_process_game_over): once it succeeds the environment steps in the same call -- what the reference's unbounded
+     * recursion amounts to */
+    int retried = 0;
+    if (e->dead == 3 && auto_reset && !simulate) { orc_game_over_env(c, e, 0); retried = e->dead != 0; }
     orc_step_env(c, e, actions + (size_t)b * c->alen, simulate ? 1 : 0);
-    if (auto_reset && !simulate) orc_game_over_env(c, e, 0);
+    if (auto_reset && !simulate && !retried) orc_game_over_env(c, e, 0);
   }
   return PPN_OK;
 }
@@ -884,7 +893,7 @@ static int field_ptr(const OCase* c, OEnv* e, ppn_field f, void** p, size_t* byt
     case PPN_F_LINE_EVENTS: A(e->lev, c->nl, uint8_t) case PPN_F_SOLVE_OUTCOME: S(e->src)
     case PPN_F_N_SOLVES: S(e->nsolve) case PPN_F_N_ITERS: S(e->niter) case PPN_F_CHRONIC_SLOT: S(e->slot)
     case PPN_F_CHRONIC_ROW: S(e->row) case PPN_F_N_LOADS_CUT: S(e->nlc) case PPN_F_N_PRODS_CUT: S(e->npc)
-    case PPN_F_EPOCH: S(e->epoch)
+    case PPN_F_EPOCH: S(e->epoch) case PPN_F_N_STEPS: S(e->nstep)
     default: return -1;
   }
 #undef A
@@ -893,7 +902,7 @@ static int field_ptr(const OCase* c, OEnv* e, ppn_field f, void** p, size_t* byt
 
 size_t orc_field_bytes(const orc_engine* E, ppn_field f) {
   void* p; size_t n;
-  if (f == PPN_F_DONE || f == PPN_F_SUCCESS) return 1;
+  if (f == PPN_F_DONE || f == PPN_F_SUCCESS || f == PPN_F_DEAD) return 1;
   if (field_ptr(&E->c, &((orc_engine*)E)->env[0], f, &p, &n)) return 0;
   return n;
 }
@@ -904,6 +913,7 @@ int orc_read(orc_engine* E, ppn_field f, void* dst, size_t bytes, int32_t to_hos
     OEnv* e = from_sim ? &E->sim[b] : &E->env[b];
     if (f == PPN_F_DONE) { ((uint8_t*)dst)[b] = (uint8_t)e->done; continue; }
     if (f == PPN_F_SUCCESS) { ((uint8_t*)dst)[b] = (uint8_t)e->succ; continue; }
+    if (f == PPN_F_DEAD) { ((uint8_t*)dst)[b] = (uint8_t)e->dead; continue; }
     void* p; size_t n;
     if (field_ptr(&E->c, e, f, &p, &n)) { snprintf(E->err, sizeof E->err, "orc_read: unsupported field %d", (int)f); return PPN_E_INVALID; }
     memcpy((char*)dst + (size_t)b * n, p, n);

@@ -308,6 +308,18 @@ class BatchedRunEnv(object):
             if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'):
                 raise RuntimeError('device_exchange=True needs an initialised "nccl" (RCCL) process group')
             return self._controller_step_device(global_actions, root, auto_reset)
+        if not getattr(self, '_warned_host_exchange', False):
+            # (until round 5 an initialised "nccl" group switched controller_step to device tensors by itself; now it is opted into)
+            self._warned_host_exchange = True
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+                    import warnings
+                    warnings.warn('BatchedRunEnv.controller_step: the process group is "nccl" (RCCL) but device_exchange=False -- the '
+                                  'exchange is staged through host arrays and numpy comes back; pass device_exchange=True to '
+                                  'BatchedRunEnv for the device-resident exchange (torch CUDA tensors back)')
+            except ImportError:
+                pass
         acts = self.scatter_from_root(global_actions, root=root)
         self.engine.step(acts, auto_reset=auto_reset)
         e = self.engine
@@ -339,11 +351,13 @@ class BatchedRunEnv(object):
         if getattr(self, '_xbuf', None) is None:
             self._xbuf = [dict(recv=torch.zeros((mx, self.action_length), dtype=torch.uint8, device=dev),
                                res=torch.zeros((mx, 3), dtype=torch.float64, device=dev),
-                               out=[torch.empty((mx, 3), dtype=torch.float64, device=dev) for _ in range(self.world_size)] if self.rank == root else None)
+                               out=None)
                           for _ in range(2)]
             self._xturn = 0
         buf = self._xbuf[self._xturn]
         self._xturn ^= 1
+        if self.rank == root and buf['out'] is None:      # (whichever call first names this rank as root: ADVICE r05)
+            buf['out'] = [torch.empty((mx, 3), dtype=torch.float64, device=dev) for _ in range(self.world_size)]
         cur = torch.cuda.current_stream(torch.device(dev))
         ext = self._engine_stream()
         parts = None

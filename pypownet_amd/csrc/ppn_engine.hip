@@ -135,6 +135,7 @@ struct ppn_engine {
   double time_ms = 0.0;
   long long launches = 0;
   int timing_every = 1; long long timed_calls = 0;
+  int last_step_form = 0;     // ppn_dim(19): kernel form of the last step launch (0 K_STEP, 1 K_STEP_PERSIST, 2 K_STEP_OBS, 3 K_ROLLOUT; + 4: two-capacity stepping)
 };
 
 static std::string g_create_error;
@@ -230,6 +231,30 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   if (timed) { (void)hipEventRecord(e1, e->stream); e->launches++; }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
+}
+
+// Explicit bracket of a GROUP of launches (two-capacity stepping: schedule pre-pass + small-storage launch + large-storage launch are
+// one step -- ADVICE r05: timing the first launch alone overstated the step-kernel figures of the configs[4] bench lines).  Subject to
+// PPN_KERNEL_TIMING_EVERY like a single timed launch; counts as ONE launch of ppn_kernel_time.
+static bool time_group_begin(ppn_engine* e) {
+#ifdef PPN_EMU
+  (void)e; return true;
+#else
+  if (e->timing_every > 1 && (e->timed_calls++ % e->timing_every) != 0) return false;
+  if (e->ev_used + 2 > e->ev.size()) {
+    for (int k = 0; k < 512; ++k) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return false; e->ev.push_back(ev); }
+  }
+  (void)hipEventRecord(e->ev[e->ev_used], e->stream);
+  return true;
+#endif
+}
+static void time_group_end(ppn_engine* e, bool began) {
+  if (!began) return;
+#ifndef PPN_EMU
+  (void)hipEventRecord(e->ev[e->ev_used + 1], e->stream);
+  e->ev_used += 2;
+#endif
+  e->launches++;
 }
 
 // Schedule pre-pass of the engines whose busbars may split (body_sched, ppn_game.inc): warms every environment's schedule cache for
@@ -548,6 +573,7 @@ extern "C" int32_t ppn_dim(const ppn_engine* e, int32_t which) {
     case 8: return d.NB; case 9: return d.LUCAP; case 10: return (int32_t)e->chronics.size(); case 11: return e->base_fill;
     case 12: return d.ECAP; case 13: return d.MCAP; case 14: return d.TCAP; case 15: return d.QCAP;
     case 17: return e->two_cap ? e->ecap_small : 0; case 18: return e->two_cap ? (int32_t)e->lds_small_cap : 0;
+    case 19: return e->last_step_form;
     default: return -1;
   }
 }
@@ -1344,6 +1370,9 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
   // kernels), for the step the launch below executes first
   const bool two_cap = e->two_cap && !simulate && n_steps == 1 && e->lds_sched <= 64 * 1024;
   if (two_cap) a.ecap_small = e->ecap_small;
+  // A step that runs the schedule pre-pass (two-capacity stepping always does) is timed as ONE group -- pre-pass, launch order and
+  // the step launch(es) between one pair of events: the pre-pass is per-step GPU work of such a step
+  bool grouped = false, group_timed = false;
   if (e->sched_prepass && e->W == 4 && e->dc.NB > e->dc.nS && !simulate && e->lds_sched <= 64 * 1024) {
     bool run = e->sched_prepass == 2 || two_cap;      // (two-capacity stepping needs every environment's class before every step)
 #ifndef PPN_EMU
@@ -1352,9 +1381,13 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     run = true;      // (the emulation build always runs it: the tests exercise the code)
 #endif
 #if !defined(PPN_ONLY_W1) && !defined(PPN_ONLY_W2)
-    if (run && launch_sched<4>(e, a, e->batch)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
+    if (run) {
+      grouped = true; group_timed = time_group_begin(e);
+      if (launch_sched<4>(e, a, e->batch)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
+    }
 #endif
   }
+  if (two_cap && !grouped) { grouped = true; group_timed = time_group_begin(e); }
   a.ecap_small = 0;
   const size_t lds_step = two_cap ? e->lds_small_cap : e->lds_bytes;
 #ifndef PPN_EMU
@@ -1368,6 +1401,8 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     if (pers) { a.work_counter = e->d_work; a.n_work = e->batch; nblocks = e->resident_slots; }
   }
 #endif
+  const bool timed1 = !grouped;      // (a lone step launch carries its own event pair)
+  int rc_step = 0;
   if (two_cap) {
     // the small-storage launch (class 0), then the large-storage one for whatever is left (class 1: plain form, one workgroup per
     // environment -- those of the other class return at once)
@@ -1375,16 +1410,18 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     as.d.ECAP = e->ecap_small; as.d.QCAP = e->ecap_small; as.d.LUCAP = 4 * e->ecap_small;
     as.cap_class = 0;
     e->lds_override = e->lds_small_cap;
-    const int rc_s = ob ? launch<K_STEP_OBS>(e, as, nblocks, true) : (as.work_counter ? launch<K_STEP_PERSIST>(e, as, nblocks, true) : launch<K_STEP>(e, as, nblocks, true));
+    rc_step = ob ? launch<K_STEP_OBS>(e, as, nblocks, false) : (as.work_counter ? launch<K_STEP_PERSIST>(e, as, nblocks, false) : launch<K_STEP>(e, as, nblocks, false));
     e->lds_override = 0;
-    if (rc_s) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
-    KArgs al = a;
-    al.cap_class = 1; al.perm = nullptr; al.work_counter = nullptr;
-    if (ob ? launch<K_STEP_OBS>(e, al, e->batch, false) : launch<K_STEP>(e, al, e->batch, false)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
-  } else
-  if (ob) { if (launch<K_STEP_OBS>(e, a, nblocks, true)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err()); }
-  else
-  if (n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, true) : (a.work_counter ? launch<K_STEP_PERSIST>(e, a, nblocks, true) : launch<K_STEP>(e, a, nblocks, true))) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+    if (!rc_step) {
+      KArgs al = a;
+      al.cap_class = 1; al.perm = nullptr; al.work_counter = nullptr;
+      rc_step = ob ? launch<K_STEP_OBS>(e, al, e->batch, false) : launch<K_STEP>(e, al, e->batch, false);
+    }
+  } else if (ob) rc_step = launch<K_STEP_OBS>(e, a, nblocks, timed1);
+  else rc_step = n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, timed1) : (a.work_counter ? launch<K_STEP_PERSIST>(e, a, nblocks, timed1) : launch<K_STEP>(e, a, nblocks, timed1));
+  if (grouped) time_group_end(e, group_timed);
+  if (rc_step) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  e->last_step_form = (ob ? 2 : (n_steps > 1 ? 3 : (a.work_counter ? 1 : 0))) + (two_cap ? 4 : 0);
   if (a.auto_reset && e->maybe_dead) {
     // environments that were already over when the step began (after ppn_reset or after steps without auto_reset) did
     // not step; they are restarted by this post-pass.  Environments that end DURING a step restart inside the step

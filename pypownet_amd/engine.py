@@ -113,6 +113,14 @@ class Engine(object):
     def lds_bytes(self):
         return self.dim(7)
 
+    STEP_FORMS = {0: 'K_STEP', 1: 'K_STEP_PERSIST', 2: 'K_STEP_OBS', 3: 'K_ROLLOUT'}
+
+    def last_step_form(self):
+        """Kernel form the last step launch took (ppn_dim 19): ('K_STEP' | 'K_STEP_PERSIST' | 'K_STEP_OBS' | 'K_ROLLOUT', stepped in
+        two capacity classes?) -- what the engine chose, not what a caller would guess from the batch size."""
+        v = self.dim(19)
+        return self.STEP_FORMS.get(v & 3, '?'), bool(v & 4)
+
     # ---- data ---------------------------------------------------------------------------------------
     def set_thermal_limits(self, limits):
         a = np.ascontiguousarray(limits, dtype=np.float64)

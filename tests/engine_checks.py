@@ -321,7 +321,7 @@ def random_actions(case, rng, batch, p_node=0.6, p_line=0.3):
 
 
 def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='newton', seed=1234, conf=None,
-                                      max_dropped=None, excuse_vm=0.0, check_obs=True, obs_every=3, obs_envs=24, **engine_kw):
+                                      max_dropped=None, excuse_vm=0.0, check_obs=True, obs_every=3, obs_envs=24, count_solves=False, **engine_kw):
     """Lock-step with the C oracle under random node-splitting / line-switching actions (dynamic Ybus rebuild every
     step, illegal-action repair, cooldowns, islanding, game overs + auto reset): flags, topology, counters bit-exact,
     voltages <= 1e-8 on live environments."""
@@ -414,6 +414,8 @@ def check_random_actions_vs_c_oracle(lib_path, envname, steps, batch, solver='ne
         stats['illegal'] += int((orc.read('ILLEGAL')[k] != 0).sum())
         stats['split_buses'] = max(stats['split_buses'], int((bt[:, case.nS:] != 4).sum(axis=1).max()))
     stats['dropped'] = int((~tracked).sum())
+    if count_solves:
+        stats['solves'] = int(orc.read('N_SOLVES').astype(np.int64).sum())
     assert stats['dropped'] <= (max(2, batch // 16) if max_dropped is None else max_dropped), 'too many environments dropped as degenerate: %d' % stats['dropped']
     return stats
 
@@ -617,7 +619,7 @@ def check_reduced_observation_layouts(lib_path, envname='default118', steps=4, b
 
 
 def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='newton', bench_limits=False, max_active_buses=None,
-                             game_over_mode='soft', conf=None, auto_reset=True):
+                             game_over_mode='soft', conf=None, auto_reset=True, limits_file='bench_limits.json', restarts=False):
     """Lock-step with the C oracle at BASELINE.json's full batch sizes (configs[1]: default14 Newton x 1024 environments,
     configs[2]: default118 Newton x 4096 environments with the cascade limits): do-nothing agent, environment e plays
     chronic (e mod n) from row (37 e) mod T, auto game-over reset.  Flags, line status, counters, chronic
@@ -629,7 +631,7 @@ def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='new
     case, cfg, chronics = load_env(envname, conf=dict(conf or {}, solver=solver))
     kw = {}
     if bench_limits:
-        with open(os.path.join(ENVS, envname, 'bench_limits.json')) as f:
+        with open(os.path.join(ENVS, envname, limits_file)) as f:
             kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
     ekw = dict(kw, game_over_mode=game_over_mode)
     if max_active_buses:
@@ -640,15 +642,20 @@ def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='new
     eng.reset(chronic_slot=slots, t0=t0)
     orc.reset(chronic_slot=slots, t0=t0)
     act = np.zeros((batch, case.action_length), dtype=np.uint8)
-    worst, n_done = 0.0, 0
+    worst, n_done, n_stuck = 0.0, 0, 0
+    fields = ('DONE', 'FLAG', 'LINES_STATUS', 'RECONNECTABLE', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES',
+              'N_ITERS', 'CASCADE_DEPTH', 'N_LOADS_CUT', 'N_PRODS_CUT', 'LINE_EVENTS', 'SOLVE_OUTCOME')
+    if restarts:      # restart-after-restart workloads: who stepped, who still is over (PPN_F_DEAD = 3), how many attempts were made
+        fields += ('N_STEPS', 'DEAD', 'EPOCH')
     for t in range(steps):
         eng.step(act, auto_reset=auto_reset)      # (2: the deferred restart of bench.py; the oracle restarts at once)
         orc.step(act, auto_reset=True)
         n_done += int(orc.read('DONE').sum())
+        if restarts:
+            n_stuck += int((orc.read('DEAD') == 3).sum())
         if (t + 1) % every and t + 1 != steps:
             continue
-        for f in ('DONE', 'FLAG', 'LINES_STATUS', 'RECONNECTABLE', 'SOFT_COUNT', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'N_SOLVES',
-                  'N_ITERS', 'CASCADE_DEPTH', 'N_LOADS_CUT', 'N_PRODS_CUT', 'LINE_EVENTS', 'SOLVE_OUTCOME'):
+        for f in fields:
             a, b = eng.read(f), orc.read(f)
             assert np.array_equal(a, b), 'step %d: %s differs for environments %s' % (
                 t, f, np.where((a != b).reshape(batch, -1).any(axis=1))[0][:10])
@@ -658,7 +665,7 @@ def check_full_size_lockstep(lib_path, envname, batch, steps, every, solver='new
         worst = max(worst, dv, da)
         assert dv <= 1e-8 and da <= 1e-8, (t, dv, da)
         np.testing.assert_allclose(eng.read('AMPS'), orc.read('AMPS'), rtol=0, atol=1e-5)
-    return dict(solves=int(orc.read('N_SOLVES').astype(np.int64).sum()), done=n_done, worst=worst,
+    return dict(solves=int(orc.read('N_SOLVES').astype(np.int64).sum()), done=n_done, worst=worst, stuck=n_stuck,
                 slots=len(set(int(s) for s in orc.read('CHRONIC_SLOT'))))
 
 
@@ -1150,6 +1157,7 @@ def check_two_capacity_stepping(lib_path, steps=16, batch=12, solver='newton', s
     fields = ('VM', 'VA', 'PF', 'AMPS', 'PG', 'QG', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES',
               'RECONNECTABLE', 'LINE_COOLDOWN', 'NODE_COOLDOWN', 'SOFT_COUNT', 'N_SOLVES', 'N_ITERS', 'N_STEPS', 'DONE', 'FLAG', 'ILLEGAL',
               'CASCADE_DEPTH', 'SOLVE_OUTCOME', 'BUS_TYPE', 'CHRONIC_ROW', 'REWARD', 'DEAD')
+    built0 = a.schedule_builds_in_kernel().copy()      # (the reset's own solve builds the reference topology's schedule)
     n_big, n_small = 0, 0
     for t in range(steps):
         acts = random_actions(case, rng, batch, p_node=0.85, p_line=0.3)
@@ -1164,6 +1172,9 @@ def check_two_capacity_stepping(lib_path, steps=16, batch=12, solver='newton', s
                 continue      # (state fields settle the deferred restarts: looked at every third step only)
             assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
         assert int((a.read('FLAG') == 4).sum()) == 0
+    # with two capacity classes a schedule built INSIDE a small-storage solve (the pre-pass foresaw another topology
+    # than the step ended up with) would be checked against the reduced capacity -- the pre-pass must have foreseen every one
+    assert np.array_equal(a.schedule_builds_in_kernel(), built0)
     a.close(); b.close()
     return dict(big=n_big, small=n_small)
 

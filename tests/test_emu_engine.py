@@ -238,3 +238,13 @@ def test_emu_step_observe_two_capacity_118(emu_lib):
         ec.check_step_observe(emu_lib, 'default118', 4, 4, 'newton', 'full')
     finally:
         del os.environ['PPN_TWO_CAP_ECAP']
+
+
+@pytest.mark.parametrize('auto_reset', [True, 2])
+def test_emu_limit_rule_110_restart_after_restart(emu_lib, auto_reset):
+    """SURVEY.md 8d's limit rule for configs[2] (limit = max(50, 1.10 x I(t = 0))): nearly every step ends in game over and some
+    restarts run out of their 64 attempts (PPN_F_DEAD = 3) -- in lock-step with the C oracle, fused and deferred restart, with
+    N_STEPS / DEAD / EPOCH compared (the GPU test runs the full 4096 x 30)."""
+    st = ec.check_full_size_lockstep(emu_lib, 'default118', 96, 14, 2, bench_limits=True, max_active_buses=118,
+                                     limits_file='bench_limits_110.json', restarts=True, auto_reset=auto_reset)
+    assert st['done'] > 800 and st['stuck'] > 0, st

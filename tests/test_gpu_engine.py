@@ -85,6 +85,28 @@ def test_gpu_full_size_default118_4096_bench_workload():
     assert st['done'] > 4096 and st['solves'] > 4096 * 60
 
 
+@pytest.mark.parametrize('auto_reset', [True, 2])
+def test_gpu_full_size_default118_4096_limit_rule_110(auto_reset):
+    """configs[2] under the limit rule SURVEY.md 8d wrote down for it -- limit = max(50, 1.10 x I(t = 0)) -- at the
+    full batch: ~98 % of the env-steps end in game over, ~8 solves per step, restart after restart (game.py:762-797 recurses), the
+    64-attempt cap and the environments it leaves over (PPN_F_DEAD = 3), which the next launch takes up again BEFORE their step.
+    4096 environments x 30 steps in lock-step with the C oracle, fused and deferred restart: N_STEPS, DEAD and EPOCH compared as
+    well (who stepped, who still is over, how many restart attempts were made)."""
+    st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 30, 5, bench_limits=True, max_active_buses=118,
+                                     limits_file='bench_limits_110.json', restarts=True, auto_reset=auto_reset)
+    assert st['done'] > 0.9 * 4096 * 30 and st['solves'] > 5 * 4096 * 30 and st['stuck'] > 0, st
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_gpu_soak_random_actions_w4_100k_solves(solver):
+    """a soak of the four-word kernels (every busbar may be active; the kernels the three GPU-only incidents of
+    rounds 2, 3 and 5 were seen on) inside the -m gpu run: 4096 environments x 24 steps of random node splitting / line switching in
+    lock-step with the C oracle -- more than 10^5 load-flow solves per solver, the default two-capacity stepping + schedule pre-pass."""
+    st = ec.check_random_actions_vs_c_oracle(HIP, 'default118', 24, 4096, solver, seed=2024, obs_every=12, excuse_vm=0.5,
+                                             max_dropped=4096 // 16, count_solves=True)
+    assert st['split_buses'] > 0 and st['illegal'] > 0 and st['solves'] > 100000, st
+
+
 def test_gpu_persistent_step_kernel(monkeypatch):
     """The PERSISTENT form of the step kernel (K_STEP_PERSIST: as many workgroups as the GPU holds, each taking the next position
     of the launch order from a counter; the engine uses it from 4 environments per resident slot on -- 8192 environments and more
@@ -368,11 +390,13 @@ def test_gpu_bench_spawns_its_ranks_when_launched_bare():
         assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith('{')]
 
 
-@pytest.mark.parametrize('single_controller', [False, True])
-def test_gpu_bench_two_ranks_share_one_gpu(single_controller, tmp_path):
+@pytest.mark.parametrize('single_controller,workload', [(False, 'cascade'), (True, 'cascade'), (False, 'split')])
+def test_gpu_bench_two_ranks_share_one_gpu(single_controller, workload, tmp_path):
     """The N > 1 path of bench.py end to end: two ranks (PPN_BENCH_BACKEND=gloo lets them share this box's one GPU; on the
     8-GPU node the driver uses RCCL), launched the way the driver launches it.  Rank r must play environments [r B, (r+1) B) of
-    the global assignment, the line must carry the aggregate of both ranks."""
+    the global assignment, the line must carry the aggregate of both ranks.  workload = 'split' (VERDICT r05 #5): BASELINE configs[4]
+    -- per-environment random node splitting -- under --gpus 2: every rank's action matrices must be ITS SLICE of the matrices a
+    single process draws for all 2 B environments (philox(1234, global env, step))."""
     import json
     import os
     import subprocess
@@ -381,25 +405,35 @@ def test_gpu_bench_two_ranks_share_one_gpu(single_controller, tmp_path):
     from helpers import ROOT
     sys.path.insert(0, ROOT)
     import bench
-    B = 256
+    B = 256 if workload == 'cascade' else 96
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', str(B),
-           '--no-cpu-baseline'] + (['--single-controller'] if single_controller else [])
+           '--no-cpu-baseline', '--workload', workload] + (['--single-controller'] if single_controller else [])
     env = dict(os.environ, PPN_BENCH_BACKEND='gloo')
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['steps'] == 4 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['config']['workload_name'] == workload
     case, conf, chronics = bench.load_workload()
     want = []
+    single = [bench.philox_node_splitting(case, np.arange(2 * B), k) for k in range(bench.SPLIT_ACTION_MATRICES)] if workload == 'split' else []
     for r in range(2):
         slots, t0 = bench.env_assignment(r * B, B, chronics)
-        want.append(zlib.crc32(slots.tobytes() + t0.tobytes()))
+        crc = zlib.crc32(slots.tobytes() + t0.tobytes())
+        for m in single:
+            crc = zlib.crc32(np.ascontiguousarray(m[r * B:(r + 1) * B]).tobytes(), crc)
+        want.append(crc)
     assert d['config']['env_assignment_crc32'] == want
+    if workload == 'split':
+        assert single[0].any()
+        assert 'W=4' in d['roofline']['kernel'] and d['config']['env_steps_executed'] == 2 * B * 4
     # the aggregate: both ranks' environments over the slowest rank's time
-    assert abs(d['value'] - 2 * B * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']
+    assert abs(d['value'] - d['config']['env_steps_executed'] / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']
+    if not single_controller:
+        assert d['value_k60'] and d['value_k60'] > 0
 
 
 def test_gpu_rccl_path_on_one_rank(tmp_path):

@@ -1,16 +1,23 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel statistics, HBM / SQ counters (separate --pmc passes, as the
 # MI355X guide prescribes), the per-phase cycle profile and the bench line of the current build.  Output: gpurun_out/<tag>/
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
+sha256sum $ROOT/pypownet_amd/libppn.so > $OUT/libppn.sha256
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --headline-only"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace -d $OUT/pmc_sq -o p --output-format csv -- $BENCH > /dev/null 2>&1
+# the counters themselves against kernels that move a known number of bytes (tools/ubench/hbm_counter_calib.hip; built in the dev container)
+if [ -x $ROOT/build/hbm_counter_calib ]; then
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/calib_write -o p --output-format csv -- $ROOT/build/hbm_counter_calib > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/calib_fetch -o p --output-format csv -- $ROOT/build/hbm_counter_calib > /dev/null 2>&1
+  python $ROOT/tools/ubench/hbm_counter_calib.py $OUT/calib_write $OUT/calib_fetch > $OUT/hbm_counter_calib.json 2> $OUT/hbm_counter_calib.err
+fi
 cd $ROOT
 # every kernel of the default bench run (headline + the other configurations: W = 1 and W = 4 step kernels too)
 cd /tmp

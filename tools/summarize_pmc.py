@@ -36,7 +36,15 @@ def main():
     w, nw = per_launch(os.path.join(src, 'pmc_write', 'p_counter_collection.csv'))
     q, nq = per_launch(os.path.join(src, 'pmc_sq', 'p_counter_collection.csv'))
     hbm = (2 * f['FETCH_SIZE'] + w['WRITE_SIZE']) * 1024
+    sha = None      # hash of the library the passes ran (tools/collect_profiles.sh writes it): bench.py refuses another build's traffic
+    if os.path.exists(os.path.join(src, 'libppn.sha256')):
+        sha = open(os.path.join(src, 'libppn.sha256')).read().split()[0]
+    calib = None    # WRITE_SIZE / FETCH_SIZE against kernels that move a known number of bytes (tools/ubench/hbm_counter_calib.hip)
+    if os.path.exists(os.path.join(src, 'hbm_counter_calib.json')):
+        calib = json.load(open(os.path.join(src, 'hbm_counter_calib.json')))
     out = {
+        'library_sha256': sha,
+        'counter_calibration': calib,
         'command': 'rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 20 --warmup 3 --headline-only '
                    '(one pass per counter group, tools/collect_profiles.sh)',
         'kernel': KERNEL + ' = K_STEP, W=2 (IEEE-118, 118 active buses), Newton flavour, batch %d environments per launch' % BATCH,
