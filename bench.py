@@ -229,6 +229,61 @@ def library_sha256():
     return h.hexdigest()
 
 
+def async_rate(eng, case, B, steps, min_ready=256, workgroups=0, mode='noop', device=0, layout='full', f32=False):
+    """CLOSED LOOP WITH AN EXTERNAL POLICY, NO BATCH BARRIER (include/ppn.h: ppn_async_start / ppn_send / ppn_recv): a torch "policy"
+    on this GPU receives whichever environments have finished their step (>= min_ready of them, the observation rows in a device
+    tensor), decides (do nothing) and sends exactly those again; stragglers keep running.  mode 'noop': the policy only passes the
+    ids on; 'reads_rows': it gathers the observation rows of the ready environments and reduces every value of them (what a real
+    policy's first layer costs in memory traffic).  Steps counted by PPN_F_N_STEPS, timed until the last one sent is complete."""
+    import torch
+    dev = 'cuda:%d' % device
+    n_obs = eng.observation_length(layout)
+    obs_t = torch.zeros((B, n_obs), dtype=torch.float32 if f32 else torch.float64, device=dev)
+    rep_t = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    ids_d = torch.zeros((B,), dtype=torch.int32, device=dev)
+    acts = torch.zeros((B, case.action_length), dtype=torch.uint8, device=dev)
+    sink = torch.zeros((B,), dtype=obs_t.dtype, device=dev)
+    torch.cuda.synchronize()
+    eng.sync()
+    n0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+    eng.async_start(obs_t.data_ptr(), obs_t.numel() * obs_t.element_size(), rep_t.data_ptr(), layout=layout,
+                    dtype=np.float32 if f32 else np.float64, workgroups=workgroups)
+    st = torch.cuda.ExternalStream(eng.async_stream_ptr(), device=dev)
+    aptr, iptr = acts.data_ptr(), ids_d.data_ptr()
+    all_ids = np.arange(B, dtype=np.int32)
+    receives = 0
+    with torch.cuda.stream(st):
+        def loop(target):
+            nonlocal receives
+            total = 0
+            while total < target:
+                ids = eng.recv(min_ready=min_ready, ids_device_ptr=iptr)
+                n = len(ids)
+                if mode == 'reads_rows':
+                    ix = ids_d[:n].long()
+                    sink.index_copy_(0, ix, obs_t.index_select(0, ix).sum(dim=1))
+                eng.send_device(ids, aptr, rows_by_env=True)
+                total += n
+                receives += 1
+            return total
+        eng.send_device(all_ids, aptr, rows_by_env=True)
+        warm = loop(3 * B)                            # warm-up (the server, torch's kernels, the allocator)
+        receives = 0
+        w0 = int(eng.async_stats()['in_flight'])      # (always B: everything received is sent again)
+        t0 = time.perf_counter()
+        timed_recv = loop(B * steps)
+        while eng.async_stats()['in_flight']:         # the steps still in flight belong to the timed region
+            eng.recv(min_ready=eng.async_stats()['in_flight'])
+        el = time.perf_counter() - t0
+    stats = eng.async_stats()
+    eng.async_stop()
+    n1 = int(eng.read('N_STEPS').astype(np.int64).sum())
+    timed = timed_recv + w0                           # steps completed inside the timed region: everything received in it, and the drain
+    assert n1 - n0 == B + warm + timed_recv, (n1 - n0, B, warm, timed_recv)      # every step sent was executed, once
+    return {'rate': timed / el, 'receives': receives, 'per_receive': timed_recv / max(receives, 1), 'workgroups': stats['workgroups'],
+            'restarts': stats['server_restarts']}
+
+
 def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=None, split=False, max_active=None, warmup=4,
                 histogram=False, lu_capacity=0, watch_capacity=0, q_plane_auto=0):
     """One of the other single-GPU configurations of BASELINE.json, timed like the headline (device-resident actions, K steps
@@ -782,6 +837,17 @@ def main():
             eng.rollout_policy('line_relief', [1.0], args.steps)
             eng.sync()
             out['config']['closed_loop_device_policy_rollout_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - p0) / (time.perf_counter() - t_p)
+        if world == 1 and not SPLIT and exchange is None and not args.no_rollout:
+            # CLOSED LOOP, EXTERNAL POLICY, NO BATCH BARRIER (round 6: ppn_send / ppn_recv, a resident step server): see async_rate
+            try:
+                for key, mode in (('closed_loop_async_external_policy_env_steps_per_s', 'noop'),
+                                  ('closed_loop_async_external_policy_reading_every_row_env_steps_per_s', 'reads_rows')):
+                    r_ = async_rate(eng, case, B, args.steps, min_ready=int(os.environ.get('PPN_BENCH_ASYNC_MIN_READY', '256')), mode=mode,
+                                    device=local_rank)
+                    out['config'][key] = r_['rate']
+                    out['config']['closed_loop_async_server_workgroups'] = r_['workgroups']
+            except Exception as ex:
+                out['config']['closed_loop_async_error'] = str(ex)[:120]
         if world == 1 and not SPLIT and not args.headline_only:
             # the same step through the host-buffer boundary (ppn_step with a host action matrix, done / flag / reward read
             # back every step): the PCIe-inclusive rate DESIGN.md quotes; never `value`

@@ -290,6 +290,70 @@ int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device
 #define PPN_POLICY_LINE_RELIEF 1
 int ppn_policy_actions(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, uint8_t* actions_out_device);
 int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, int32_t n_steps);
+/* ---- asynchronous stepping for EXTERNAL policies: send / recv (libppn 0.3) ------------------------------------------------------
+ * The reference's consumers are agents that LOOK at the observation and then act (pypownet/runner.py:72-103: obs -> agent.act ->
+ * env.step; agent.py:268-311).  Stepped synchronously, a batch advances at the pace of its slowest environment: every ppn_step lasts
+ * as long as the longest cascade of the batch (one environment in 500 runs 20 Newton iterations where the median runs 3).  An
+ * asynchronous session removes that barrier for policies that live OUTSIDE the engine (a torch module, a host program):
+ *
+ *     ppn_async_start(e, &cfg);                         a step server becomes resident on the GPU
+ *     ppn_send(e, all_env_ids, batch, actions, ...);    every environment gets its first action
+ *     loop:  ppn_recv(e, min_ready, ...) -> the ids of >= min_ready environments whose step is complete (their observation rows and
+ *                                            report rows are in the caller's device buffers); stragglers keep running
+ *            policy(observation rows of those ids) -> actions
+ *            ppn_send(e, those ids, n, actions, ...)
+ *     ppn_async_stop(e);
+ *
+ * Every environment is on its own clock; per environment the trajectory is bit for bit that of ppn_step_observe(auto_reset = 1)
+ * called with the same actions in the same order (tests: check_async_equals_stepping) -- environments never interact.
+ *   step semantics   Game.step with the fused restart (auto_reset = 1): the observation row of an environment whose episode ended
+ *                    shows the restarted episode, its report row (done, flag, reward sum) the step that ended it -- what an agent
+ *                    behind RunEnv.step / process_game_over sees (runner.py:81-96).
+ *   ownership        obs_device / report_device are DEVICE buffers of the caller, [batch x row]: row `env` is rewritten by every
+ *                    step of environment `env`, and is stable from the ppn_recv that returned `env` until the ppn_send that sends it
+ *                    again.  An environment may be in flight once: sending it again before it was received is PPN_E_STATE.
+ *   streams          the server runs on a stream of its own; ppn_send's work is queued on ppn_async_stream(e) (a non-blocking HIP
+ *                    stream): device-side action / id buffers handed to ppn_send must be complete ON THAT STREAM (run the policy
+ *                    on it, or make it wait for the policy's event) and must stay untouched until the enqueue kernel has read
+ *                    them (stream order again).  ppn_recv is a host-side wait on a completion ring in pinned memory: it
+ *                    synchronises nothing.  Do not call hipDeviceSynchronize (torch.cuda.synchronize) inside a session: it waits
+ *                    for the resident server, i.e. for its idle timeout.
+ *   other calls      any other entry point of this header called during a session first SETTLES it: waits for the steps in flight,
+ *                    stops the server, does its work on a quiet engine; completions not yet received stay receivable and the next
+ *                    ppn_send starts the server again.  (Correct, not fast: keep reads of state out of the loop.)
+ *   liveness         the server leaves by itself when nothing has been published for cfg.idle_timeout_ms (default 1000): a host that
+ *                    died leaves no kernel spinning.  A host that was merely slow loses nothing: the next ppn_send / ppn_recv finds
+ *                    the server gone, re-publishes the steps it had not started and launches it again. */
+typedef struct ppn_async_config {
+  int32_t struct_size;        /* = sizeof(ppn_async_config) */
+  int32_t layout;             /* observation layout as in ppn_read_observation: 0 full, 1 minimalist, 2 AC minimalist */
+  int32_t as_f32;             /* rows as float32 instead of float64 */
+  int32_t workgroups;         /* resident server workgroups; 0 = what the GPU holds minus one per CU (room for the policy's kernels) */
+  int32_t idle_timeout_ms;    /* 0 = 1000 */
+  int32_t reserved;
+  void* obs_device;           /* [batch x ppn_observation_length(layout)] rows, or NULL: no observation is written */
+  size_t obs_bytes;
+  double* report_device;      /* [batch x 3] (done, flag, reward sum) rows = PPN_F_STEP_REPORT, or NULL */
+} ppn_async_config;
+int ppn_async_start(ppn_engine* e, const ppn_async_config* cfg);
+/* Publishes one step each for the n listed environments.  env_ids: HOST int32 [n] (what ppn_recv returned, or any order of one's own).
+ * actions: u8 rows, host (actions_on_device = 0) or device memory; rows_by_env = 0: [n x action_len], row i belongs to env_ids[i];
+ * rows_by_env = 1: a [batch x action_len] matrix indexed by environment (a policy that writes its choices in place). */
+int ppn_send(ppn_engine* e, const int32_t* env_ids, int32_t n, const uint8_t* actions, int32_t actions_on_device, int32_t rows_by_env);
+/* Waits until at least min(min_ready, steps in flight) steps are complete (timeout_ms < 0: for as long as it takes; on a timeout
+ * fewer are returned, possibly none) and hands out at most max_n of them, in completion order: env_ids_host [max_n] receives the
+ * environment indices, *n_out their number; env_ids_device (may be NULL) receives the same int32 values through an asynchronous copy
+ * on ppn_async_stream(e) -- for a policy that gathers its observation rows on that stream. */
+int ppn_recv(ppn_engine* e, int32_t min_ready, int32_t max_n, int32_t timeout_ms, int32_t* env_ids_host, int32_t* n_out,
+             int32_t* env_ids_device);
+/* Ends the session: waits for the steps in flight, stops the server.  Completions not yet received are dropped. */
+int ppn_async_stop(ppn_engine* e);
+/* hipStream_t of ppn_send's device work (NULL outside a session). */
+void* ppn_async_stream(ppn_engine* e);
+/* 0 steps in flight (sent, not yet received), 1 resident server workgroups, 2 times the server had to be started again after it
+ * had left on its idle timeout, 3 steps re-published by those restarts */
+int64_t ppn_async_stat(const ppn_engine* e, int32_t which);
+
 /* Topology-action search (the reference's search agents call RunEnv.simulate once per candidate,
  * pypownet/agent.py:161-325): candidate c forks the CURRENT state of environment env_ids[c] and plays
  * Game.simulate(actions[c]) on it (game.py:887-943); any number of candidates per environment, one kernel launch.

@@ -50,6 +50,13 @@ class PpnMpcBatch(C.Structure):
                 ('success', C.POINTER(C.c_uint8)), ('outcome', C.POINTER(C.c_int32))]
 
 
+class PpnAsyncConfig(C.Structure):
+    """ppn_async_config (include/ppn.h): the asynchronous session's observation layout, server size and the caller's device buffers."""
+    _fields_ = [('struct_size', C.c_int32), ('layout', C.c_int32), ('as_f32', C.c_int32), ('workgroups', C.c_int32),
+                ('idle_timeout_ms', C.c_int32), ('reserved', C.c_int32), ('obs_device', C.c_void_p), ('obs_bytes', C.c_size_t),
+                ('report_device', C.c_void_p)]
+
+
 class PpnChronic(C.Structure):
     _fields_ = [('T', C.c_int32)] + [(k, C.POINTER(C.c_float)) for k in (
         'prods_p', 'prods_v', 'loads_p', 'loads_q', 'prods_p_planned', 'prods_v_planned', 'loads_p_planned',
@@ -82,7 +89,8 @@ EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limit
            'ppn_step', 'ppn_process_game_over', 'ppn_is_action_valid', 'ppn_runpf_batch', 'ppn_field_bytes',
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
            'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays', 'ppn_rollout',
-           'ppn_policy_actions', 'ppn_rollout_policy', 'ppn_step_observe']
+           'ppn_policy_actions', 'ppn_rollout_policy', 'ppn_step_observe', 'ppn_async_start', 'ppn_send', 'ppn_recv', 'ppn_async_stop',
+           'ppn_async_stream', 'ppn_async_stat']
 
 
 def _preload_torch_hip_runtime():
@@ -179,6 +187,18 @@ def bind_signatures(lib, full_abi=True):
         lib.ppn_rollout_policy.restype = C.c_int
         lib.ppn_step_observe.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t]
         lib.ppn_step_observe.restype = C.c_int
+        lib.ppn_async_start.argtypes = [vp, C.POINTER(PpnAsyncConfig)]
+        lib.ppn_async_start.restype = C.c_int
+        lib.ppn_send.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32]
+        lib.ppn_send.restype = C.c_int
+        lib.ppn_recv.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.POINTER(C.c_int32), vp]
+        lib.ppn_recv.restype = C.c_int
+        lib.ppn_async_stop.argtypes = [vp]
+        lib.ppn_async_stop.restype = C.c_int
+        lib.ppn_async_stream.argtypes = [vp]
+        lib.ppn_async_stream.restype = vp
+        lib.ppn_async_stat.argtypes = [vp, C.c_int32]
+        lib.ppn_async_stat.restype = C.c_int64
     lib.ppn_stream.argtypes = [vp]
     lib.ppn_stream.restype = vp
     lib.ppn_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

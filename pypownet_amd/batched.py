@@ -207,6 +207,66 @@ class BatchedRunEnv(object):
         e.rollout_policy(policy, list(params), int(n_steps))
         return e.read('RETURN'), e.read('DONE').astype(bool), e.read('FLAG'), e.read('N_STEPS')
 
+    # ---- asynchronous session: send / recv (include/ppn.h, ppn_async_start) ----------------------------------------------
+    # EnvPool-style boundary for policies that live outside the engine: every environment is stepped again as soon as the policy has
+    # decided for it; nobody waits for the longest cascade of the batch.  Device tensors only (the policy is a torch module on this
+    # GPU); Engine.send / Engine.recv take host arrays.
+    def async_start(self, layout='full', obs_dtype=None, workgroups=0, idle_timeout_ms=0):
+        """Starts the resident step server.  The observation rows ([batch x observation_length(layout)], float64 or float32) and the
+        report rows ([batch x 3]: done, flag, reward sum) live in torch CUDA tensors of this object: ``self.async_obs`` / ``self.async_report``;
+        row e is rewritten by every step of environment e and is stable from the recv that returned e to the send that sends it again."""
+        import torch
+        dev = 'cuda:%d' % self.device
+        tdt = torch.float32 if self._is_f32(obs_dtype) else torch.float64
+        self.async_obs = torch.zeros((self.batch, self.engine.observation_length(layout)), dtype=tdt, device=dev)
+        self.async_report = torch.zeros((self.batch, 3), dtype=torch.float64, device=dev)
+        self._async_ids = torch.zeros((self.batch,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(self.device)      # (the zero fills ran on torch's stream; the server runs on its own)
+        self.engine.async_start(self.async_obs.data_ptr(), self.async_obs.numel() * self.async_obs.element_size(), self.async_report.data_ptr(),
+                                layout=layout, dtype=np.float32 if tdt == torch.float32 else np.float64, workgroups=workgroups,
+                                idle_timeout_ms=idle_timeout_ms)
+        self._async_stream = torch.cuda.ExternalStream(self.engine.async_stream_ptr(), device=dev)
+
+    def async_stream(self):
+        """The session's HIP stream as a torch stream: run the policy under ``torch.cuda.stream(env.async_stream())`` and every send
+        is ordered behind the kernels that produced its actions, every gather of a recv behind the copy of its ids -- no host
+        synchronisation anywhere in the loop."""
+        return self._async_stream
+
+    def send(self, env_ids, actions, rows_by_env=False):
+        """env_ids: int tensor / array [n]; actions: uint8 CUDA tensor [n x action_length] (row i for env_ids[i]) or, rows_by_env,
+        [batch x action_length] indexed by environment.  The tensor must have been produced on ``async_stream()`` (or that stream must
+        wait for its producer) and must not be overwritten before the stream has passed this call."""
+        import torch
+        ids = env_ids.cpu().numpy() if torch.is_tensor(env_ids) else np.asarray(env_ids)
+        t = self._as_device_tensor(actions)
+        if t is None:
+            self.engine.send(ids, actions, rows_by_env=rows_by_env)
+            return
+        assert tuple(t.shape) == ((self.batch if rows_by_env else len(ids)), self.action_length)
+        cur = torch.cuda.current_stream(t.device)
+        if cur.cuda_stream != self._async_stream.cuda_stream:
+            self._async_stream.wait_stream(cur)      # the actions were produced on another stream: the session's stream waits for it
+        self._keep_alive = t                          # (a temporary made by .contiguous() must outlive the enqueue kernel)
+        self.engine.send_device(ids, t.data_ptr(), rows_by_env=rows_by_env)
+
+    def recv(self, min_ready=1, max_n=None, timeout_ms=-1, gather=True):
+        """-> (ids [n] int32 CUDA tensor, observation rows [n x len], report rows [n x 3]) of >= min_ready environments whose step is
+        complete (gather=False: (ids, None, None) -- index ``async_obs`` / ``async_report`` yourself).  The gathers are queued on the
+        session's stream behind the copy of the ids; the host does not wait for them."""
+        import torch
+        ids_h = self.engine.recv(min_ready=min_ready, max_n=max_n, timeout_ms=timeout_ms, ids_device_ptr=self._async_ids.data_ptr())
+        n = len(ids_h)
+        with torch.cuda.stream(self._async_stream):
+            ids = self._async_ids[:n].clone()        # (the staging tensor is overwritten by the next recv)
+            if not gather:
+                return ids, None, None
+            ix = ids.long()
+            return ids, self.async_obs.index_select(0, ix), self.async_report.index_select(0, ix)
+
+    def async_stop(self):
+        self.engine.async_stop()
+
     def search(self, candidate_actions, want_obs=False):
         """Topology-action search (what the reference's search agents do with one ``simulate`` call per candidate,
         pypownet/agent.py:161-325): ``candidate_actions`` uint8 [batch x K x action_length], host array or device tensor; every

@@ -135,6 +135,26 @@ struct ppn_engine {
   double time_ms = 0.0;
   long long launches = 0;
   int timing_every = 1; long long timed_calls = 0;
+  // ---- asynchronous session (ppn_async.inc: ppn_async_start / ppn_send / ppn_recv / ppn_async_stop) ----------------------------
+  struct Async {
+    bool active = false;            // a session is configured
+    bool server_running = false;    // the K_SERVE launch is believed to be resident (it may have left on its idle timeout)
+    int layout = 0, f32 = 0, sections = 0, stride = 0;
+    void* obs = nullptr; double* report_out = nullptr;
+    int n_wg = 0, n_wg_req = 0, idle_ms = 1000;
+    unsigned mask = 0;              // ring size - 1 (a power of two >= 2 x batch)
+    int* d_items = nullptr; unsigned* d_ctl = nullptr;
+    unsigned long long* h_done = nullptr;                      // pinned: completion ring
+    int *h_ids = nullptr, *h_out = nullptr; u8* h_acts = nullptr;      // pinned: ids / action rows of sends, ids of receives
+    unsigned long long published = 0;   // items pushed into the ring since the session began (re-publications included)
+    unsigned long long received = 0;    // completions handed to the caller (= index of the next ring entry to look at)
+    long long n_inflight = 0;           // environments sent and not yet received
+    long long restarts = 0, republished = 0;
+    std::vector<u8> inflight;
+    std::vector<u8> mark;               // scratch of the recovery pass
+    hipStream_t s_server = 0, s_async = 0;
+  } as;
+  hipStream_t launch_stream = 0;  // (launch_w: the stream of the launch in flight when it is not `stream`)
   int last_step_form = 0;     // ppn_dim(19): kernel form of the last step launch (0 K_STEP, 1 K_STEP_PERSIST, 2 K_STEP_OBS, 3 K_ROLLOUT; + 4: two-capacity stepping)
 };
 
@@ -188,6 +208,26 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   unsigned char* base = (unsigned char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
   Smem S;
   ppn_carve(a.d, W, NT, base, &S, KIND == K_VALID || KIND == K_OBS || KIND == K_POLICY);
+  if (KIND == K_SERVE) {
+    // the step server of an asynchronous session, emulated: every item published so far is played NOW, in a pseudo-random order (on
+    // the GPU they complete in whatever order their cascades end), each followed by its completion record
+    unsigned head = a.q_ctl[0]; const unsigned tail = a.q_ctl[1];
+    std::vector<unsigned> order;
+    for (unsigned k = head; k != tail; ++k) order.push_back(k);
+    unsigned x = 2463534242u ^ (head * 2654435761u);
+    for (size_t i = order.size(); i > 1; --i) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; std::swap(order[i - 1], order[x % i]); }
+    for (unsigned k : order) {
+      const int e_ = a.q_items[k & a.q_mask];
+      memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));
+      body_step<W, NT>(a.d, a.st, S, a.actions, 0, 1, a.restart_prio, e_, 0);
+      if (a.obs) { if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, e_, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, e_, 0); }
+      if (a.report_out) for (int j = 0; j < 3; ++j) a.report_out[3 * (size_t)e_ + j] = a.st.report[3 * (size_t)e_ + j];
+      const unsigned c = a.q_ctl[3]++;
+      a.q_done[c & a.q_mask] = ((unsigned long long)(c + 1u) << 32) | (unsigned)e_;
+    }
+    a.q_ctl[0] = tail;
+    return 0;
+  }
   if (KIND == K_POLICY_ROLLOUT) {      // the items in their hand-out order: (step, environment)
     for (int item = 0; item < a.n_work; ++item) {
       const int s_ = item / a.n_envs, k_ = item - s_ * a.n_envs;
@@ -227,7 +267,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     e0 = e->ev[e->ev_used++]; e1 = e->ev[e->ev_used++];
     (void)hipEventRecord(e0, e->stream);
   }
-  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), (KIND == K_VALID || KIND == K_OBS || KIND == K_POLICY) ? e->lds_small : (e->lds_override ? e->lds_override : e->lds_bytes), e->stream, a);
+  hipLaunchKernelGGL((ppn_kernel<W, KIND, NT>), dim3(nblocks), dim3(64), (KIND == K_VALID || KIND == K_OBS || KIND == K_POLICY) ? e->lds_small : (e->lds_override ? e->lds_override : e->lds_bytes), e->launch_stream ? e->launch_stream : e->stream, a);
   if (timed) { (void)hipEventRecord(e1, e->stream); e->launches++; }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
@@ -288,7 +328,7 @@ static int launch_sched(ppn_engine* e, const KArgs& a, int nblocks) {
 // the others only as NT = 0.
 template <int W, int KIND>
 static int launch_nt(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
-  constexpr bool solves = (KIND == K_STEP || KIND == K_STEP_OBS || KIND == K_STEP_PERSIST || KIND == K_ROLLOUT || KIND == K_POLICY_ROLLOUT || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
+  constexpr bool solves = (KIND == K_STEP || KIND == K_STEP_OBS || KIND == K_STEP_PERSIST || KIND == K_ROLLOUT || KIND == K_POLICY_ROLLOUT || KIND == K_SERVE || KIND == K_GAMEOVER || KIND == K_RESET || KIND == K_RUNPF);
   if (solves && e->newton) return launch_w<W, KIND, solves ? 1 : 0>(e, a, nblocks, timed);
   return launch_w<W, KIND, 0>(e, a, nblocks, timed);
 }
@@ -313,7 +353,7 @@ static int set_lds_attr(size_t bytes) {
   int rc = 0;
 #define PPN_ATTR(K, N) rc |= hipFuncSetAttribute((const void*)ppn_kernel<W, K, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess;
   PPN_ATTR(K_STEP, 0) PPN_ATTR(K_STEP, 1) PPN_ATTR(K_GAMEOVER, 0) PPN_ATTR(K_GAMEOVER, 1) PPN_ATTR(K_RESET, 0) PPN_ATTR(K_RESET, 1)
-  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1) PPN_ATTR(K_STEP_PERSIST, 0) PPN_ATTR(K_STEP_PERSIST, 1) PPN_ATTR(K_POLICY_ROLLOUT, 0) PPN_ATTR(K_POLICY_ROLLOUT, 1) PPN_ATTR(K_POLICY, 0) PPN_ATTR(K_STEP_OBS, 0) PPN_ATTR(K_STEP_OBS, 1)
+  PPN_ATTR(K_RUNPF, 0) PPN_ATTR(K_RUNPF, 1) PPN_ATTR(K_VALID, 0) PPN_ATTR(K_OBS, 0) PPN_ATTR(K_ROLLOUT, 0) PPN_ATTR(K_ROLLOUT, 1) PPN_ATTR(K_STEP_PERSIST, 0) PPN_ATTR(K_STEP_PERSIST, 1) PPN_ATTR(K_POLICY_ROLLOUT, 0) PPN_ATTR(K_POLICY_ROLLOUT, 1) PPN_ATTR(K_POLICY, 0) PPN_ATTR(K_STEP_OBS, 0) PPN_ATTR(K_STEP_OBS, 1) PPN_ATTR(K_SERVE, 0) PPN_ATTR(K_SERVE, 1)
 #undef PPN_ATTR
   return rc;
 }
@@ -382,6 +422,9 @@ static int filled_pairs(int nS, const std::vector<int>& f, const std::vector<int
 // ---------------------------------------------------------------------------------------------------------------------
 // Every entry point makes the engine's device current first: engines of different GPUs may live in one process (the
 // stream, the events and the allocations all belong to e->device).
+static int async_quiesce(ppn_engine* e);
+// every entry point but the session's own settles a running asynchronous session first (include/ppn.h, "other calls")
+#define PPN_QUIESCE(e_) do { if ((e_) && (e_)->as.server_running) { const int rq_ = async_quiesce(e_); if (rq_) return rq_; } } while (0)
 static inline void enter(const ppn_engine* e) {
 #ifndef PPN_EMU
   if (e) (void)hipSetDevice(e->device);
@@ -394,11 +437,13 @@ static inline void enter(const ppn_engine* e) {
 // (emulation build only: lane order of the LANE_LOOP regions, see ppn_device.h)
 extern "C" void ppn_emu_set_lane_order(int mode) { ppn_emu_order_mode_ = mode; ppn_emu_order_state_ = (unsigned)mode * 2654435761u + 12345u; if (!ppn_emu_order_state_) ppn_emu_order_state_ = 1u; }
 #endif
-extern "C" const char* ppn_version(void) { return "pypownet_amd libppn 0.2 (gfx950)"; }
+extern "C" const char* ppn_version(void) { return "pypownet_amd libppn 0.3 (gfx950)"; }
 
 extern "C" const char* ppn_last_error(const ppn_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
+static void async_free(ppn_engine* e);
 static void free_all(ppn_engine* e) {
+  async_free(e);
   for (void* p : e->allocs) dev_free(p);
   for (void* p : e->chronic_allocs) dev_free(p);
   for (void* p : e->cand_allocs) dev_free(p);
@@ -411,6 +456,7 @@ static void free_all(ppn_engine* e) {
 
 extern "C" int ppn_destroy(ppn_engine* e) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e) return PPN_E_INVALID;
   free_all(e);
   delete e;
@@ -892,12 +938,14 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
 
 extern "C" int ppn_set_thermal_limits(ppn_engine* e, const double* limits) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !limits) return PPN_E_INVALID;
   return dev_h2d((void*)e->dc.limits, limits, sizeof(double) * e->dc.nl, e->stream) ? fail(e, PPN_E_HIP, "limits upload failed") : PPN_OK;
 }
 
 extern "C" int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !c || c->T <= 0) return PPN_E_INVALID;
   if (slot < 0 || slot > (int)e->chronics.size()) return fail(e, PPN_E_INVALID, "chronic slots must be loaded in order");
   const DevCase& d = e->dc;
@@ -1079,6 +1127,7 @@ static int settle_restarts(ppn_engine* e) {
 
 extern "C" int ppn_reset(ppn_engine* e, const int32_t* env_ids, int32_t n, const int32_t* chronic_slot, const int32_t* t0) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e) return PPN_E_INVALID;
   { int rcs = settle_restarts(e); if (rcs) return rcs; }
   int rc = sync_chronics(e);
@@ -1328,6 +1377,7 @@ static void default_reward(double* rw, double c) {   // parameters/default14/rew
 
 extern "C" int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !p) return PPN_E_INVALID;
   const double* v = (const double*)p;
   for (int k = 0; k < 13; ++k) e->dc.R.rw[k] = v[k];
@@ -1440,6 +1490,7 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
 extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate,
                         int32_t auto_reset) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !actions) return PPN_E_INVALID;
   return step_launch(e, actions, actions_on_device, simulate, auto_reset, 1, 0);
 }
@@ -1447,6 +1498,7 @@ extern "C" int ppn_step(ppn_engine* e, const uint8_t* actions, int32_t actions_o
 extern "C" int ppn_step_observe(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t auto_reset,
                                 int32_t layout, int32_t as_f32, void* obs_device, size_t bytes) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !actions || !obs_device || layout < 0 || layout > 2) return PPN_E_INVALID;
   if (auto_reset != 0 && auto_reset != 1) return fail(e, PPN_E_INVALID, "ppn_step_observe: auto_reset must be 0 or 1 (a deferred restart would leave the observation of the ended episode in the rows)");
   const int len = obs_length(e->dc, layout);
@@ -1459,6 +1511,7 @@ extern "C" int ppn_step_observe(ppn_engine* e, const uint8_t* actions, int32_t a
 extern "C" int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t n_steps,
                            int32_t per_step_actions, int32_t auto_reset) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !actions || n_steps <= 0) return PPN_E_INVALID;
   if (e->maybe_dead && auto_reset) {      // environments that are over right now are restarted first: every environment plays all its steps
     int rc = ppn_process_game_over(e, nullptr);
@@ -1480,6 +1533,7 @@ static int fill_policy(ppn_engine* e, KArgs* a, int32_t policy, const double* pa
 
 extern "C" int ppn_policy_actions(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, uint8_t* actions_out_device) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !actions_out_device) return PPN_E_INVALID;
   { int rcs = settle_restarts(e); if (rcs) return rcs; }      // the policy looks at the state
   KArgs a = make_args(e, false);
@@ -1491,6 +1545,7 @@ extern "C" int ppn_policy_actions(ppn_engine* e, int32_t policy, const double* p
 
 extern "C" int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, int32_t n_steps) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || n_steps <= 0) return PPN_E_INVALID;
   if ((long long)n_steps * e->batch > 0x7fffff00LL) return fail(e, PPN_E_INVALID, "ppn_rollout_policy: batch x n_steps exceeds the work counter");
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
@@ -1554,6 +1609,7 @@ static int gather_rows(ppn_engine* e, void* dst, const void* src, const int* d_i
 extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device,
                                        const int32_t* env_ids, int32_t n) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !actions || !env_ids || n <= 0) return PPN_E_INVALID;
   { int rcs = settle_restarts(e); if (rcs) return rcs; }
   for (int c = 0; c < n; ++c) if (env_ids[c] < 0 || env_ids[c] >= e->batch) return fail(e, PPN_E_INVALID, "ppn_simulate_candidates: environment %d out of range", env_ids[c]);
@@ -1630,6 +1686,7 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
 
 extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e) return PPN_E_INVALID;
   { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (e->chronics_dirty) { int rc = sync_chronics(e); if (rc) return rc; }
@@ -1644,6 +1701,7 @@ extern "C" int ppn_process_game_over(ppn_engine* e, const uint8_t* env_mask) {
 
 extern "C" int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_t* valid) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !actions || !valid) return PPN_E_INVALID;
   { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (dev_h2d(e->d_actions, actions, (size_t)e->batch * e->dc.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
@@ -1656,6 +1714,7 @@ extern "C" int ppn_is_action_valid(ppn_engine* e, const uint8_t* actions, uint8_
 
 extern "C" int ppn_runpf_batch(ppn_engine* e) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e) return PPN_E_INVALID;
   { int rcs = settle_restarts(e); if (rcs) return rcs; }
   KArgs a = make_args(e, false);
@@ -1664,9 +1723,11 @@ extern "C" int ppn_runpf_batch(ppn_engine* e) {
 }
 
 #include "ppn_mpc.inc"
+#include "ppn_async.inc"
 
 extern "C" int ppn_sync(ppn_engine* e) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e) return PPN_E_INVALID;
   { int rcs = settle_restarts(e); if (rcs) return rcs; }
 #ifndef PPN_EMU
@@ -1677,6 +1738,7 @@ extern "C" int ppn_sync(ppn_engine* e) {
 
 extern "C" int ppn_wait(ppn_engine* e) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e) return PPN_E_INVALID;
 #ifndef PPN_EMU
   if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
@@ -1694,6 +1756,7 @@ extern "C" void* ppn_stream(ppn_engine* e) {
 
 extern "C" int ppn_kernel_time(ppn_engine* e, int32_t reset, double* total_ms, int64_t* launches) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e) return PPN_E_INVALID;
 #ifndef PPN_EMU
   if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, PPN_E_HIP, "stream sync failed: %s", dev_err());
@@ -1718,6 +1781,7 @@ static int obs_length(const DevCase& d, int layout) {     // environment.py:406-
 extern "C" int ppn_read_observation(ppn_engine* e, int32_t layout, int32_t as_f32, void* dst, size_t bytes, int32_t to_host,
                                     int32_t from_simulation) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !dst || layout < 0 || layout > 2) return PPN_E_INVALID;
   if (from_simulation == 0) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read_observation: no candidates have been simulated");
@@ -1742,6 +1806,7 @@ extern "C" int32_t ppn_observation_length(const ppn_engine* e, int32_t layout) {
 
 extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int32_t to_host, int32_t from_simulation) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !dst) return PPN_E_INVALID;
   if (from_simulation == 2 && e->n_cand <= 0) return fail(e, PPN_E_INVALID, "ppn_read: no candidates have been simulated");
   const DevState& s = (from_simulation == 2) ? e->cand : (from_simulation ? e->sim : e->st);
@@ -1765,6 +1830,7 @@ extern "C" int ppn_read(ppn_engine* e, ppn_field f, void* dst, size_t bytes, int
 
 extern "C" int ppn_write(ppn_engine* e, ppn_field f, const void* src, size_t bytes) {
   enter(e);
+  PPN_QUIESCE(e);
   if (!e || !src) return PPN_E_INVALID;
   if ((int)f != 100) { int rcs = settle_restarts(e); if (rcs) return rcs; }
   FieldInfo fi; bool w;

@@ -239,6 +239,56 @@ class Engine(object):
         pid, keep, pp, n = self._policy_args(policy, params)
         self._check(self._lib.ppn_rollout_policy(self._h, pid, pp, n, int(n_steps)), 'ppn_rollout_policy')
 
+    # ---- asynchronous session: send / recv for policies that live outside the engine (include/ppn.h) ----------------------------
+    LAYOUT_IDS = {'full': 0, 'minimalist': 1, 'ac_minimalist': 2}
+
+    def async_start(self, obs_ptr=0, obs_bytes=0, report_ptr=0, layout='full', dtype=np.float64, workgroups=0, idle_timeout_ms=0):
+        """Starts the step server (ppn_async_start).  ``obs_ptr`` / ``report_ptr``: DEVICE buffers of the caller, [batch x
+        observation_length(layout)] of ``dtype`` and [batch x 3] float64 (done, flag, reward sum); 0 = not written."""
+        cfg = _lib.PpnAsyncConfig()
+        cfg.struct_size = C.sizeof(_lib.PpnAsyncConfig)
+        cfg.layout = self.LAYOUT_IDS[layout] if isinstance(layout, str) else int(layout)
+        cfg.as_f32 = 1 if np.dtype(dtype) == np.dtype(np.float32) else 0
+        cfg.workgroups, cfg.idle_timeout_ms = int(workgroups), int(idle_timeout_ms)
+        cfg.obs_device, cfg.obs_bytes, cfg.report_device = int(obs_ptr) or None, int(obs_bytes), int(report_ptr) or None
+        self._recv_buf = np.empty(self.batch, dtype=np.int32)
+        self._check(self._lib.ppn_async_start(self._h, C.byref(cfg)), 'ppn_async_start')
+
+    def send(self, env_ids, actions, rows_by_env=False):
+        """One step each for the listed environments (ppn_send).  ``actions``: a host uint8 array -- [len(env_ids) x action_length], or
+        [batch x action_length] with ``rows_by_env`` -- or the integer address of such rows in DEVICE memory (see ``send_device``)."""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        a = np.ascontiguousarray(actions, dtype=np.uint8)
+        assert a.shape == ((self.batch if rows_by_env else len(ids)), self.case.action_length), a.shape
+        self._check(self._lib.ppn_send(self._h, ids.ctypes.data, len(ids), a.ctypes.data, 0, 1 if rows_by_env else 0), 'ppn_send')
+
+    def send_device(self, env_ids, actions_ptr, rows_by_env=False):
+        """The same with the action rows in DEVICE memory at ``actions_ptr`` -- complete on ``async_stream_ptr()`` and left alone until
+        that stream has passed the send (include/ppn.h, "streams")."""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        self._check(self._lib.ppn_send(self._h, ids.ctypes.data, len(ids), C.c_void_p(int(actions_ptr)), 1, 1 if rows_by_env else 0), 'ppn_send')
+
+    def recv(self, min_ready=1, max_n=None, timeout_ms=-1, ids_device_ptr=0):
+        """Environments whose step is complete (ppn_recv): at least min(min_ready, in flight) of them unless the timeout strikes, in
+        completion order, as an int32 array (a view of a buffer the next recv overwrites).  ``ids_device_ptr``: DEVICE int32 buffer that
+        receives the same ids through an asynchronous copy on the session's stream."""
+        n = C.c_int32(0)
+        cap = self.batch if max_n is None else min(int(max_n), self.batch)
+        self._check(self._lib.ppn_recv(self._h, int(min_ready), cap, int(timeout_ms), self._recv_buf.ctypes.data, C.byref(n),
+                                       C.c_void_p(int(ids_device_ptr)) if ids_device_ptr else None), 'ppn_recv')
+        return self._recv_buf[:n.value]
+
+    def async_stop(self):
+        self._check(self._lib.ppn_async_stop(self._h), 'ppn_async_stop')
+
+    def async_stream_ptr(self):
+        """hipStream_t of the session's device work as an integer (torch.cuda.ExternalStream wraps it); 0 outside a session."""
+        return int(self._lib.ppn_async_stream(self._h) or 0)
+
+    def async_stats(self):
+        return dict(in_flight=int(self._lib.ppn_async_stat(self._h, 0)), workgroups=int(self._lib.ppn_async_stat(self._h, 1)),
+                    server_restarts=int(self._lib.ppn_async_stat(self._h, 2)), republished=int(self._lib.ppn_async_stat(self._h, 3)))
+
     def simulate(self, actions):
         a = self._actions(actions)
         self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 1, 0), 'ppn_step(simulate)')

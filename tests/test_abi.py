@@ -55,6 +55,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu\n", sizeof(ppn_case), sizeof(ppn_rules), sizeof(ppn_chronic),
          offsetof(ppn_rules, n_timesteps_consecutive_soft_overflow_breaks), offsetof(ppn_rules, lu_capacity));
   printf("%zu %zu %zu\n", offsetof(ppn_rules, q_plane_auto), sizeof(ppn_mpc_batch), offsetof(ppn_mpc_batch, success));
+  printf("%zu %zu %zu\n", sizeof(ppn_async_config), offsetof(ppn_async_config, obs_device), offsetof(ppn_async_config, report_device));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -63,7 +64,8 @@ int main(void) {
         out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
     got = [C.sizeof(_lib.PpnCase), C.sizeof(_lib.PpnRules), C.sizeof(_lib.PpnChronic),
            _lib.PpnRules.n_timesteps_consecutive_soft_overflow_breaks.offset, _lib.PpnRules.lu_capacity.offset,
-           _lib.PpnRules.q_plane_auto.offset, C.sizeof(_lib.PpnMpcBatch), _lib.PpnMpcBatch.success.offset]
+           _lib.PpnRules.q_plane_auto.offset, C.sizeof(_lib.PpnMpcBatch), _lib.PpnMpcBatch.success.offset,
+           C.sizeof(_lib.PpnAsyncConfig), _lib.PpnAsyncConfig.obs_device.offset, _lib.PpnAsyncConfig.report_device.offset]
     assert [int(v) for v in out] == got
 
 

@@ -248,3 +248,41 @@ def test_emu_limit_rule_110_restart_after_restart(emu_lib, auto_reset):
     st = ec.check_full_size_lockstep(emu_lib, 'default118', 96, 14, 2, bench_limits=True, max_active_buses=118,
                                      limits_file='bench_limits_110.json', restarts=True, auto_reset=auto_reset)
     assert st['done'] > 800 and st['stuck'] > 0, st
+
+
+@pytest.mark.parametrize('envname,solver,layout,dtype,min_ready,kw', [
+    ('default118', 'newton', 'full', 'float64', 3, dict(max_active_buses=118)),
+    ('default118', 'fdxb', 'minimalist', 'float32', 1, dict(max_active_buses=118)),
+    ('default14_for_tests_alpha', 'newton', 'ac_minimalist', 'float64', 6, dict(bench_limits=False)),
+    ('default118', 'newton', 'full', 'float64', 4, dict())])        # (four-word kernels: every busbar may be active)
+def test_emu_async_send_recv_equals_stepping(emu_lib, envname, solver, layout, dtype, min_ready, kw):
+    """ppn_send / ppn_recv (host logic, rings, settle-on-other-calls; the emulated server completes items in a shuffled order)."""
+    st = ec.check_async_equals_stepping(emu_lib, envname, batch=7, n_steps=12, solver=solver, layout=layout, dtype=np.dtype(dtype),
+                                        min_ready=min_ready, rows_by_env=(min_ready == 1), **kw)
+    assert st['steps'] == 7 * 12 and st['settled'] >= 1
+
+
+def test_emu_async_session_errors(emu_lib):
+    from helpers import load_env
+    from harness import engine_with_library
+    from pypownet_amd.engine import EngineError
+    case, cfg, chronics = load_env('default14_for_tests', conf={'solver': 'newton'})
+    eng = engine_with_library(emu_lib, case, cfg, 4, chronics=chronics)
+    eng.reset()
+    act = np.zeros((4, case.action_length), dtype=np.uint8)
+    with pytest.raises(EngineError):
+        eng.send([0], act[:1])                       # no session
+    eng.async_start()
+    eng.send([0, 1], act[:2])
+    with pytest.raises(EngineError):
+        eng.send([1], act[:1])                       # in flight
+    with pytest.raises(EngineError):
+        eng.send([2, 7], act[:2])                    # out of range -- and environment 2 must not be left marked in flight
+    eng.send([2], act[:1])
+    got = set()
+    while len(got) < 3:
+        got |= set(int(v) for v in eng.recv(min_ready=1))
+    assert got == {0, 1, 2} and len(eng.recv(min_ready=1, timeout_ms=0)) == 0
+    assert eng.async_stats()['in_flight'] == 0
+    eng.async_stop()
+    eng.close()

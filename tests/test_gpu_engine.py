@@ -626,3 +626,66 @@ def test_gpu_step_observe_bench_workload_2048():
     from helpers import load_env
     case, _, _ = load_env('default118')
     ec.check_step_observe(HIP, 'default118', 2048, 6, 'newton', 'full', np.float64, thermal_limits=lim, max_active_buses=case.nS)
+
+
+@pytest.mark.parametrize('envname,batch,steps,solver,layout,dtype,min_ready,kw', [
+    ('default14', 32, 30, 'newton', 'full', 'float64', 8, dict(bench_limits=False)),
+    ('default118', 2048, 10, 'newton', 'full', 'float64', 512, dict(max_active_buses=118, settle_at=5)),
+    ('default118', 512, 12, 'fdxb', 'minimalist', 'float32', 1, dict(max_active_buses=118, rows_by_env=True)),
+    ('default118', 256, 10, 'newton', 'ac_minimalist', 'float64', 64, dict(device_actions=True)),       # four-word kernels
+    ('default118', 4096, 6, 'newton', 'full', 'float64', 1024, dict(max_active_buses=118, device_actions=True))])
+def test_gpu_async_send_recv_equals_stepping(envname, batch, steps, solver, layout, dtype, min_ready, kw):
+    """the asynchronous batch boundary for EXTERNAL policies (ppn_async_start / ppn_send / ppn_recv over the C ABI:
+    a resident step server, a completion ring in pinned memory) -- per environment the same trajectory, observation rows and report
+    rows, bit for bit, as ppn_step(auto_reset = 1) with the same actions; host and device action rows, both row conventions, a call of
+    another entry point in the middle of the session (it settles the session), one- to four-word kernels, up to the full 4096."""
+    st = ec.check_async_equals_stepping(None, envname, batch=batch, n_steps=steps, solver=solver, layout=layout, dtype=np.dtype(dtype),
+                                        min_ready=min_ready, **kw)
+    assert st['steps'] == batch * steps and st['done'] > 0 and st['restarts'] == 0, st
+    if batch >= 2048:
+        assert st['apart'] >= 0 and st['receives'] > steps, st      # (more receives than synchronous steps: nobody waited for the batch)
+
+
+def test_gpu_async_server_leaves_on_idle_timeout_and_is_restarted():
+    """Liveness: the resident server must not outlive a host that went away -- it leaves when nothing has been published for its idle
+    timeout -- and a host that was merely slow loses nothing: the next call finds the server gone, re-publishes what it had not started
+    and launches it again.  Here: a 150 ms timeout and a host that sleeps 0.6 s in the middle of the session; same trajectories."""
+    st = ec.check_async_equals_stepping(None, 'default118', batch=256, n_steps=8, solver='newton', min_ready=64, max_active_buses=118,
+                                        idle_timeout_ms=150, pause_s=0.6)
+    assert st['steps'] == 256 * 8 and st['restarts'] >= 1, st
+
+
+def test_gpu_batched_send_recv_with_a_torch_policy():
+    """BatchedRunEnv.send / recv: torch tensors in, torch tensors out, the policy's work ordered on the session's stream -- a closed
+    loop in which every environment is stepped again as soon as a (torch) policy has looked at its observation row."""
+    import torch
+    from helpers import ENVS
+    from pypownet_amd.batched import BatchedRunEnv
+    B, K = 1024, 6
+    env = BatchedRunEnv(os.path.join(ENVS, 'default118'), 'level0', B, device=0, config_overrides={'solver': 'newton'}, max_active_buses=118)
+    ref = BatchedRunEnv(os.path.join(ENVS, 'default118'), 'level0', B, device=0, config_overrides={'solver': 'newton'}, max_active_buses=118)
+    env.reset(); ref.reset()
+    env.engine.process_game_over(); ref.engine.process_game_over()
+    for _ in range(K):
+        ref.engine.step(np.zeros((B, env.action_length), dtype=np.uint8), auto_reset=True)
+    env.async_start(layout='minimalist', obs_dtype=torch.float32)
+    stream = env.async_stream()
+    with torch.cuda.stream(stream):
+        acts = torch.zeros((B, env.action_length), dtype=torch.uint8, device='cuda:0')
+        env.send(torch.arange(B, dtype=torch.int32), acts, rows_by_env=True)
+        steps = torch.zeros(B, dtype=torch.int64)
+        total, seen_nan = 0, 0
+        while total < B * K:
+            ids, obs, rep = env.recv(min_ready=128)
+            assert obs.is_cuda and rep.is_cuda and obs.shape[0] == len(ids) and obs.dtype == torch.float32
+            seen_nan += int(torch.isnan(obs).any())
+            ids_c = ids.cpu().long()
+            steps[ids_c] += 1
+            total += len(ids_c)
+            again = ids_c[steps[ids_c] < K]
+            if len(again):
+                env.send(again, acts, rows_by_env=True)      # the "policy": do nothing, in place
+    env.async_stop()
+    assert int(steps.min()) == K and int(steps.max()) == K
+    for f in ('VM', 'LINES_STATUS', 'N_STEPS', 'N_SOLVES', 'CHRONIC_ROW', 'RETURN'):
+        assert np.array_equal(env.engine.read(f), ref.engine.read(f), equal_nan=True), f
