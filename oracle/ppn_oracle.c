@@ -201,6 +201,12 @@ static void lu_solve(const SpLU* f, const double* b, double* x) {
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* Diagnostic for DESIGN.md ("is there a PROVABLE early exit from a Newton solve that will not converge?"): over the
+ * Newton solves that run out of their iterations, how many reach a state from which the remaining iterations are decided --
+ * an update that is exactly zero (a fixed point with a mismatch above the tolerance), or an iterate that repeats an earlier one bit
+ * for bit (a cycle).  Counted only when ORC_CYCLE_STATS is set in the environment; read with orc_debug_cycle_stats. */
+static long long g_cyc[6];      /* Newton solves, ran out of iterations, of those: zero update seen, exact repeat seen, NaN/inf mismatch seen, at iteration (sum) */
+static int g_cyc_on = -1;
 /* One runpf.  Returns 0 converged, 1 diverged, 2 not connexe (exception path of grid.py:228-231).           */
 typedef struct { int n; int* deg; int* col; cplx* val; } YMat;
 
@@ -360,7 +366,14 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
     for (int q = 0; q < m; ++q) pm[q] = q;
     cplx* V = (cplx*)malloc(n * sizeof(cplx)); cplx* Ib = (cplx*)malloc(n * sizeof(cplx));
     double* F = (double*)malloc((m > 0 ? m : 1) * sizeof(double)); double* dx = (double*)malloc((m > 0 ? m : 1) * sizeof(double));
+    if (g_cyc_on < 0) g_cyc_on = getenv("ORC_CYCLE_STATS") != NULL;
+    double* hist = g_cyc_on ? (double*)malloc((size_t)(R->max_it + 2) * 2 * n * sizeof(double)) : NULL;
+    int cyc_zero = 0, cyc_rep = 0, cyc_nan = 0, cyc_at = 0;
     for (int it = 0;; ++it) {
+      if (hist && it <= R->max_it) {
+        memcpy(hist + (size_t)it * 2 * n, vm, n * sizeof(double)); memcpy(hist + (size_t)it * 2 * n + n, va, n * sizeof(double));
+        for (int j = 0; j < it && !cyc_rep; ++j) if (!memcmp(hist + (size_t)j * 2 * n, hist + (size_t)it * 2 * n, 2 * n * sizeof(double))) { cyc_rep = 1; if (!cyc_at) cyc_at = it; }
+      }
       for (int i = 0; i < n; ++i) V[i] = vm[i] * cexp(I * va[i]);
       double normF = 0.0;
       for (int i = 0; i < n; ++i) {
@@ -372,6 +385,7 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
         if (ivm[i] >= 0) { F[ivm[i]] = cimag(mis); const double a = fabs(cimag(mis)); if (a > normF || a != a) if (normF == normF) normF = a; }
       }
       if (normF < R->tol) { success = 1; break; }
+      if (hist && !(normF == normF && normF < 1e300) && !cyc_nan) { cyc_nan = 1; if (!cyc_at) cyc_at = it; }
       if (it >= R->max_it) break;
       ++*iters;
       /* dSbus_dV */
@@ -399,6 +413,7 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
       if (bad || lu_factor(&LU, &J, pm)) { lu_free(&LU); rm_free(&J); rc = 4; break; }
       lu_solve(&LU, F, dx);
       lu_free(&LU); rm_free(&J);
+      if (hist && !cyc_zero) { int z = 1; for (int q = 0; q < m; ++q) if (dx[q] != 0.0) { z = 0; break; } if (z) { cyc_zero = 1; if (!cyc_at) cyc_at = it; } }
       for (int i = 0; i < n; ++i) {
         if (ith[i] >= 0) va[i] -= dx[ith[i]];
         if (ivm[i] >= 0) vm[i] -= dx[ivm[i]];
@@ -406,6 +421,10 @@ static int orc_solve(const OCase* c, OEnv* e, int* iters) {
         vm[i] = cabs(v); va[i] = carg(v);
         if (vm[i] < e->min_vm) e->min_vm = vm[i];   /* test diagnostic (an iterate at V = 0 exactly turns the next one into NaN) */
       }
+    }
+    if (hist) {
+#pragma omp critical
+      { g_cyc[0]++; if (!success && rc != 4) { g_cyc[1]++; g_cyc[2] += cyc_zero; g_cyc[3] += cyc_rep; g_cyc[4] += cyc_nan; g_cyc[5] += cyc_at; } }
     }
     free(ith); free(ivm); free(pm); free(V); free(Ib); free(F); free(dx);
     if (rc == 4) goto done;
@@ -934,6 +953,7 @@ int orc_write(orc_engine* E, ppn_field f, const void* src, size_t bytes) {
 int orc_sync(orc_engine* E) { (void)E; return PPN_OK; }
 /* oracle-only diagnostic (tests): smallest |V| of an active bus over the successful solves of each environment's last step
  * (before any game-over restart); lets the lock-step tests set aside voltage-collapse cases, which are rounding luck. */
+int orc_debug_cycle_stats(long long* out6) { for (int k = 0; k < 6; ++k) out6[k] = g_cyc[k]; return PPN_OK; }
 int orc_debug_min_vm(orc_engine* E, double* out) { for (int k = 0; k < E->batch; ++k) out[k] = E->env[k].min_vm; return PPN_OK; }
 void* orc_stream(orc_engine* E) { (void)E; return NULL; }
 int orc_kernel_time(orc_engine* E, int32_t reset, double* ms, int64_t* n) { (void)E; (void)reset; if (ms) *ms = 0; if (n) *n = 0; return PPN_OK; }

@@ -98,6 +98,7 @@ struct ppn_engine {
   // the rest (usually none: the workgroups of that launch return at once).  Which class an environment is in is decided BEFORE its
   // step touches anything, by the schedule pre-pass, from the pattern size of the schedule the step will solve on (the small Q
   // plane is as large as the small P plane, so nothing else can overflow).  PPN_TWO_CAP=0 turns it off.
+  bool cand_cache = true;       // PPN_CAND_CACHE=0: candidate slots do not keep their schedules (every fork copies the environment's, as until round 5)
   bool two_cap = false, two_cap_allowed = true;
   int two_cap_forced = 0;         // (tests, PPN_TWO_CAP_ECAP: a small storage so small that some environments need the large one)
   int ecap_small = 0;             // pattern capacity (P plane = Q plane) of the small storage
@@ -308,8 +309,8 @@ static int launch_sched(ppn_engine* e, const KArgs& a, int nblocks) {
   ppn_carve_sched(a.d, W, base, &S);
   for (int env = 0; env < nblocks; ++env) {
     memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, e->lds_sched);
-    if (e->newton) body_sched<W, PPN_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0, a.ecap_small);
-    else body_sched<W, PPN_FD_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0, a.ecap_small);
+    if (e->newton) body_sched<W, PPN_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0, a.ecap_small, a.ssrc);
+    else body_sched<W, PPN_FD_TAIL_BUSES, 64>(a.d, a.st, S, a.actions, a.auto_reset, env, 0, a.ecap_small, a.ssrc);
   }
   return 0;
 #else
@@ -923,6 +924,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   { const char* v = getenv("PPN_LAUNCH_ORDER"); if (v && v[0] == '0') e->order_launches = false; }
   { const char* v = getenv("PPN_KERNEL_TIMING_EVERY"); if (v && atoi(v) > 0) e->timing_every = atoi(v); }
   { const char* v = getenv("PPN_RESTART_PRIO"); if (v) e->restart_prio = (float)atof(v); }
+  { const char* v = getenv("PPN_CAND_CACHE"); if (v && v[0] == '0') e->cand_cache = false; }
   e->d_ids = dalloc<int>(e, (size_t)3 * batch);
   e->d_obs = dalloc<double>(e, (size_t)batch * d.obslen);
   if (e->mem_failed) { free_all(e); delete e; return fail(nullptr, PPN_E_HIP, "device allocation or upload failed: %s", dev_err()); }
@@ -1645,8 +1647,11 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
     if (dev_h2d(e->d_cand_actions, actions, (size_t)n * d.alen, e->stream)) return fail(e, PPN_E_HIP, "action upload failed");
     dact = e->d_cand_actions;
   }
-  // fork: every per-environment array of the live state, plus the schedule cache and its records (a candidate that does
-  // not move an element to another busbar solves on the schedule its environment already has)
+  // fork: every per-environment array of the live state.  The schedule caches: engines whose busbars may split run the schedule
+  // pre-pass over the candidate slots (body_sched, candidate mode: own cache / the environment's / build -- a slot KEEPS its schedule
+  // across calls); the others copy the environment's cache and records into the slot as before (a candidate that does not move an
+  // element to another busbar solves on the schedule its environment already has, anything else is built inside the solve)
+  const bool cand_prepass = e->sched_prepass && e->W == 4 && e->dc.NB > e->dc.nS && e->lds_sched <= 64 * 1024 && e->cand_cache;
   int rc = 0;
   DevState* dst = &e->cand; const DevState* src = &e->st;
 #define GR(m, type, cnt) rc |= gather_rows(e, dst->m, src->m, e->d_cand_ids, env_ids, sizeof(type) * (size_t)(cnt), n);
@@ -1657,20 +1662,25 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
   GR(done, u8, 1) GR(dead, u8, 1) GR(succ, u8, 1) GR(btype, u8, d.nrows) GR(flag, int, 1) GR(ill, int, 1)
   GR(depth, int, 1) GR(nsolve, int, 1) GR(niter, int, 1) GR(slot, int, 1) GR(row, int, 1) GR(nlc, int, 1)
   GR(npc, int, 1) GR(epoch, int, 1) GR(prow, int, 1) GR(lev, u8, d.nl) GR(src, int, 1) GR(draws, unsigned, 1)
-  GR(ws_tri, u64, d.TCAP) GR(ws_pair, u64, d.MCAP) GR(ws_piv, unsigned, d.NB) GR(ws_cache, u8, d.cache_stride)
+  if (!cand_prepass) { GR(ws_tri, u64, d.TCAP) GR(ws_pair, u64, d.MCAP) GR(ws_piv, unsigned, d.NB) GR(ws_cache, u8, d.cache_stride) }
 #undef GR
   if (rc) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err());
   KArgs a = make_args(e, false);
   a.st = e->cand;
   a.actions = dact; a.sim = 1; a.auto_reset = 0;
-  if (e->two_cap && e->lds_sched <= 64 * 1024) {
-    // two-capacity stepping for the candidates as well (round 5): the pre-pass builds every candidate's schedule in its slot's cache
-    // and classes it; the small-storage launch plays four candidates per CU, the large-storage one whatever does not fit
+  const bool two_cap = e->two_cap && cand_prepass;
 #if !defined(PPN_ONLY_W1) && !defined(PPN_ONLY_W2)
-    a.ecap_small = e->ecap_small;
+  if (cand_prepass) {
+    a.ssrc.cache = e->st.ws_cache; a.ssrc.tri = e->st.ws_tri; a.ssrc.pair = e->st.ws_pair; a.ssrc.piv = e->st.ws_piv; a.ssrc.ids = e->d_cand_ids;
+    a.ecap_small = two_cap ? e->ecap_small : 0;
     if (launch_sched<4>(e, a, n)) return fail(e, PPN_E_HIP, "schedule pre-pass launch failed: %s", dev_err());
     a.ecap_small = 0;
+    memset(&a.ssrc, 0, sizeof a.ssrc);
+  }
 #endif
+  if (two_cap) {
+    // two-capacity stepping for the candidates as well (round 5): the pre-pass has classed every candidate's schedule; the
+    // small-storage launch plays four candidates per CU, the large-storage one whatever does not fit
     KArgs as = a;
     as.d.ECAP = e->ecap_small; as.d.QCAP = e->ecap_small; as.d.LUCAP = 4 * e->ecap_small;
     as.cap_class = 0;

@@ -1349,3 +1349,47 @@ def check_async_equals_stepping(lib_path, envname='default118', batch=8, n_steps
     return dict(steps=total, receives=n_recv, settled=n_settled, done=int(sum(int(r[:, 0].sum()) for r in want_rep)),
                 apart=int(step_of.max() - step_of.min()), restarts=st['server_restarts'], republished=st['republished'],
                 workgroups=st['workgroups'], out_of_order=int(order_seen[:batch] != sorted(order_seen[:batch])))
+
+
+def check_candidate_schedule_cache(lib_path, batch=6, k=4, rounds=6, seed=17, solver='newton'):
+    """Round 6: the candidate slots of ppn_simulate_candidates KEEP their schedules across calls (body_sched, candidate mode: the
+    slot's own cache / the environment's / a build).  Against an engine whose slots are refilled from the environment's cache at every
+    fork (PPN_CAND_CACHE=0, the behaviour until round 5): the same candidates evaluated again (slot hits), new ones (builds), after
+    environment steps that move elements (the environments' own topologies change underneath: stale slots must be rebuilt, candidates
+    that move nothing take the environment's schedule) -- every candidate's outcome bit for bit the same."""
+    import os
+    case, cfg, chronics = load_env('default118', conf={'solver': solver})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics)
+    os.environ['PPN_CAND_CACHE'] = '0'
+    try:
+        b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics)
+    finally:
+        os.environ.pop('PPN_CAND_CACHE', None)
+    rng = np.random.default_rng(seed)
+    for e in (a, b):
+        e.reset()
+    env_ids = np.repeat(np.arange(batch, dtype=np.int32), k)
+    fields = ('FLAG', 'ILLEGAL', 'DONE', 'LINES_STATUS', 'PRODS_NODES', 'LOADS_NODES', 'LINES_OR_NODES', 'LINES_EX_NODES', 'AMPS', 'VM', 'VA',
+              'BUS_TYPE', 'CASCADE_DEPTH', 'N_SOLVES', 'N_ITERS', 'REWARD', 'SOLVE_OUTCOME')
+    cands = None
+    n_split = 0
+    for r in range(rounds):
+        if r % 3 != 1:      # (every third round evaluates the SAME candidates again: every slot that moved something is a hit)
+            cands = np.stack([random_actions(case, rng, batch, p_node=0.9, p_line=0.3) for _ in range(k)], axis=1).reshape(batch * k, -1)
+            cands[::k] = 0      # candidate 0 of every environment: do nothing (the environment's own schedule)
+        for e in (a, b):
+            e.simulate_candidates(cands, env_ids)
+        for f in fields:
+            assert np.array_equal(a.read(f, simulation=2), b.read(f, simulation=2), equal_nan=True), (r, f)
+        assert np.array_equal(a.observations(simulation=2), b.observations(simulation=2), equal_nan=True)
+        assert int((a.read('FLAG', simulation=2) == 4).sum()) == 0
+        n_split += int(a.read('LINES_OR_NODES', simulation=2).any(axis=1).sum())
+        if r % 2 == 1:      # the environments move on, with node switches of their own
+            acts = random_actions(case, rng, batch, p_node=0.8, p_line=0.2)
+            for e in (a, b):
+                e.step(acts, auto_reset=True)
+            for f in ('VM', 'LINES_OR_NODES', 'N_SOLVES'):
+                assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (r, f)
+    a.close(); b.close()
+    return n_split

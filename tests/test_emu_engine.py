@@ -286,3 +286,8 @@ def test_emu_async_session_errors(emu_lib):
     assert eng.async_stats()['in_flight'] == 0
     eng.async_stop()
     eng.close()
+
+
+@pytest.mark.parametrize('solver', ['newton', 'fdxb'])
+def test_emu_candidate_slots_keep_their_schedules(emu_lib, solver):
+    assert ec.check_candidate_schedule_cache(emu_lib, batch=5, k=4, rounds=6, solver=solver) > 0

@@ -94,7 +94,7 @@ def test_gpu_full_size_default118_4096_limit_rule_110(auto_reset):
     well (who stepped, who still is over, how many restart attempts were made)."""
     st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 30, 5, bench_limits=True, max_active_buses=118,
                                      limits_file='bench_limits_110.json', restarts=True, auto_reset=auto_reset)
-    assert st['done'] > 0.9 * 4096 * 30 and st['solves'] > 5 * 4096 * 30 and st['stuck'] > 0, st
+    assert st['done'] > 0.6 * 4096 * 30 and st['solves'] > 8 * 4096 * 30 and st['stuck'] > 0, st
 
 
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
@@ -689,3 +689,10 @@ def test_gpu_batched_send_recv_with_a_torch_policy():
     assert int(steps.min()) == K and int(steps.max()) == K
     for f in ('VM', 'LINES_STATUS', 'N_STEPS', 'N_SOLVES', 'CHRONIC_ROW', 'RETURN'):
         assert np.array_equal(env.engine.read(f), ref.engine.read(f), equal_nan=True), f
+
+
+@pytest.mark.parametrize('solver,batch,k', [('newton', 128, 8), ('fdxb', 64, 4)])
+def test_gpu_candidate_slots_keep_their_schedules(solver, batch, k):
+    """Round 6: ppn_simulate_candidates' slots keep their schedules across calls -- same outcomes, bit for bit, as
+    refilling every slot from its environment at every fork (PPN_CAND_CACHE=0)."""
+    assert ec.check_candidate_schedule_cache(None, batch=batch, k=k, rounds=8, solver=solver) > 0

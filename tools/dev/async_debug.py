@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Where does an asynchronous session lose time?  Per-iteration host timestamps of the recv / send loop (tools/async_rate.py's loop),
+the largest gaps, and the server-restart counter as it moves.   python tools/dev/async_debug.py [batch] [steps] [variant ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import bench  # noqa: E402
+
+
+def run(variant, B, K):
+    import torch
+    from pypownet_amd.engine import Engine
+    case, conf, chronics = bench.load_workload()
+    eng = Engine(case, conf, B, device=0, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
+    slots, t0 = bench.env_assignment(0, B, chronics)
+    eng.reset(chronic_slot=slots, t0=t0)
+    n_obs = eng.observation_length('full')
+    obs_t = torch.zeros((B, n_obs), dtype=torch.float64, device='cuda')
+    rep_t = torch.zeros((B, 3), dtype=torch.float64, device='cuda')
+    ids_d = torch.zeros((B,), dtype=torch.int32, device='cuda')
+    acts = torch.zeros((B, case.action_length), dtype=torch.uint8, device='cuda')
+    acts_h = np.zeros((B, case.action_length), dtype=np.uint8)
+    torch.cuda.synchronize()
+    eng.sync()
+    eng.async_start(obs_t.data_ptr(), obs_t.numel() * 8, rep_t.data_ptr())
+    st = torch.cuda.ExternalStream(eng.async_stream_ptr(), device='cuda')
+    stamps = []
+    t_begin = time.perf_counter()
+    with torch.cuda.stream(st):
+        if 'hostact' in variant:
+            eng.send(np.arange(B, dtype=np.int32), acts_h, rows_by_env=True)
+        else:
+            eng.send_device(np.arange(B, dtype=np.int32), acts.data_ptr(), rows_by_env=True)
+        total = 0
+        while total < B * K:
+            ta = time.perf_counter()
+            ids = eng.recv(min_ready=256, ids_device_ptr=ids_d.data_ptr() if 'idsdev' in variant else 0)
+            tb = time.perf_counter()
+            n = len(ids)
+            if 'hostact' in variant:
+                eng.send(ids, acts_h, rows_by_env=True)
+            else:
+                eng.send_device(ids, acts.data_ptr(), rows_by_env=True)
+            tc = time.perf_counter()
+            total += n
+            stamps.append((ta - t_begin, tb - ta, tc - tb, n, eng.async_stats()['server_restarts']))
+        td = time.perf_counter()
+        while eng.async_stats()['in_flight']:
+            eng.recv(min_ready=eng.async_stats()['in_flight'])
+        te = time.perf_counter()
+    el = time.perf_counter() - t_begin
+    s = eng.async_stats()
+    eng.async_stop()
+    tf = time.perf_counter()
+    a = np.array([(x[1], x[2], x[3]) for x in stamps])
+    worst = sorted(stamps, key=lambda x: -x[1])[:4]
+    print('%-16s B=%d K=%d: %.3f M env-steps/s overall; %d receives, recv wait mean %.1f us max %.1f ms, send mean %.1f us max %.1f ms, drain %.2f ms, stop %.2f ms, restarts %d republished %d, resident %d' % (
+        variant, B, K, (total + B) / el / 1e6, len(stamps), a[:, 0].mean() * 1e6, a[:, 0].max() * 1e3, a[:, 1].mean() * 1e6, a[:, 1].max() * 1e3,
+        (te - td) * 1e3, (tf - te) * 1e3, s['server_restarts'], s['republished'], s['workgroups']), flush=True)
+    for w in worst:
+        print('    at %.1f ms: recv waited %.2f ms for %d environments (restarts so far %d)' % (w[0] * 1e3, w[1] * 1e3, w[3], w[4]), flush=True)
+    eng.close()
+
+
+if __name__ == '__main__':
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    for v in (sys.argv[3:] or ['devact', 'devact+idsdev', 'hostact']):
+        run(v, B, K)
