@@ -144,7 +144,7 @@ struct ppn_engine {
     void* obs = nullptr; double* report_out = nullptr;
     int n_wg = 0, n_wg_req = 0, idle_ms = 1000;
     unsigned mask = 0;              // ring size - 1 (a power of two >= 2 x batch)
-    int* d_items = nullptr; unsigned* d_ctl = nullptr;
+    unsigned long long* d_items = nullptr; unsigned* d_ctl = nullptr;
     unsigned long long* h_done = nullptr;                      // pinned: completion ring
     int *h_ids = nullptr, *h_out = nullptr; u8* h_acts = nullptr;      // pinned: ids / action rows of sends, ids of receives
     unsigned long long published = 0;   // items pushed into the ring since the session began (re-publications included)
@@ -213,12 +213,13 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     // the step server of an asynchronous session, emulated: every item published so far is played NOW, in a pseudo-random order (on
     // the GPU they complete in whatever order their cascades end), each followed by its completion record
     unsigned head = a.q_ctl[0]; const unsigned tail = a.q_ctl[1];
+    for (unsigned k = head; k != tail; ++k) if ((unsigned)(a.q_items[k & a.q_mask] >> 32) != k + 1u) return -1;      // (every published slot carries its stamp)
     std::vector<unsigned> order;
     for (unsigned k = head; k != tail; ++k) order.push_back(k);
     unsigned x = 2463534242u ^ (head * 2654435761u);
     for (size_t i = order.size(); i > 1; --i) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; std::swap(order[i - 1], order[x % i]); }
     for (unsigned k : order) {
-      const int e_ = a.q_items[k & a.q_mask];
+      const int e_ = (int)(unsigned)(a.q_items[k & a.q_mask] & 0xFFFFFFFFull);
       memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));
       body_step<W, NT>(a.d, a.st, S, a.actions, 0, 1, a.restart_prio, e_, 0);
       if (a.obs) { if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, e_, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, e_, 0); }

@@ -17,7 +17,12 @@ def run(variant, B, K):
     import torch
     from pypownet_amd.engine import Engine
     case, conf, chronics = bench.load_workload()
-    eng = Engine(case, conf, B, device=0, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
+    lib = os.environ.get('PPN_DEBUG_LIB')      # (developer builds of the library, driven through the test harness)
+    if lib:
+        from harness import engine_with_library
+        eng = engine_with_library(lib, case, conf, B, device=0, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
+    else:
+        eng = Engine(case, conf, B, device=0, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
     slots, t0 = bench.env_assignment(0, B, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
     n_obs = eng.observation_length('full')
@@ -28,7 +33,19 @@ def run(variant, B, K):
     acts_h = np.zeros((B, case.action_length), dtype=np.uint8)
     torch.cuda.synchronize()
     eng.sync()
-    eng.async_start(obs_t.data_ptr(), obs_t.numel() * 8, rep_t.data_ptr())
+    if 'rollout' in variant:      # reference point: the device-policy rollout kernel (no host in the loop, no observation)
+        eng.rollout_policy('do_nothing', [], 3); eng.sync()
+        t_ = time.perf_counter(); eng.rollout_policy('do_nothing', [], K); eng.sync()
+        print('%-16s B=%d K=%d: %.3f M env-steps/s (ppn_rollout_policy, do-nothing)' % (variant, B, K, B * K / (time.perf_counter() - t_) / 1e6), flush=True)
+        eng.close()
+        return
+    wg = [int(v[2:]) for v in variant.split('+') if v.startswith('wg')]
+    mr = [int(v[2:]) for v in variant.split('+') if v.startswith('mr')]
+    mr = mr[0] if mr else 256
+    if 'noobs' in variant:
+        eng.async_start(0, 0, rep_t.data_ptr(), workgroups=wg[0] if wg else 0)
+    else:
+        eng.async_start(obs_t.data_ptr(), obs_t.numel() * 8, rep_t.data_ptr(), workgroups=wg[0] if wg else 0)
     st = torch.cuda.ExternalStream(eng.async_stream_ptr(), device='cuda')
     stamps = []
     t_begin = time.perf_counter()
@@ -40,7 +57,7 @@ def run(variant, B, K):
         total = 0
         while total < B * K:
             ta = time.perf_counter()
-            ids = eng.recv(min_ready=256, ids_device_ptr=ids_d.data_ptr() if 'idsdev' in variant else 0)
+            ids = eng.recv(min_ready=mr, ids_device_ptr=ids_d.data_ptr() if 'idsdev' in variant else 0)
             tb = time.perf_counter()
             n = len(ids)
             if 'hostact' in variant:
@@ -60,7 +77,7 @@ def run(variant, B, K):
     tf = time.perf_counter()
     a = np.array([(x[1], x[2], x[3]) for x in stamps])
     worst = sorted(stamps, key=lambda x: -x[1])[:4]
-    print('%-16s B=%d K=%d: %.3f M env-steps/s overall; %d receives, recv wait mean %.1f us max %.1f ms, send mean %.1f us max %.1f ms, drain %.2f ms, stop %.2f ms, restarts %d republished %d, resident %d' % (
+    print('%-22s B=%d K=%d: %.3f M env-steps/s overall; %d receives, recv wait mean %.1f us max %.1f ms, send mean %.1f us max %.1f ms, drain %.2f ms, stop %.2f ms, restarts %d republished %d, resident %d' % (
         variant, B, K, (total + B) / el / 1e6, len(stamps), a[:, 0].mean() * 1e6, a[:, 0].max() * 1e3, a[:, 1].mean() * 1e6, a[:, 1].max() * 1e3,
         (te - td) * 1e3, (tf - te) * 1e3, s['server_restarts'], s['republished'], s['workgroups']), flush=True)
     for w in worst:
