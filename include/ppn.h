@@ -316,12 +316,14 @@ int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int3
  *                    stream): device-side action / id buffers handed to ppn_send must be complete ON THAT STREAM (run the policy
  *                    on it, or make it wait for the policy's event) and must stay untouched until the enqueue kernel has read
  *                    them (stream order again).  ppn_recv is a host-side wait on a completion ring in pinned memory: it
- *                    synchronises nothing.  Do not call hipDeviceSynchronize (torch.cuda.synchronize) inside a session: it waits
- *                    for the resident server, i.e. for its idle timeout.
+ *                    synchronises nothing.  Anything that waits for the WHOLE device inside a session (hipDeviceSynchronize /
+ *                    torch.cuda.synchronize, hipFree, the first launch of a kernel whose module is not loaded yet) waits for the
+ *                    resident server, i.e. for its idle timeout: correct, but it costs that long -- warm the policy up before
+ *                    the session and keep such calls out of the loop.
  *   other calls      any other entry point of this header called during a session first SETTLES it: waits for the steps in flight,
  *                    stops the server, does its work on a quiet engine; completions not yet received stay receivable and the next
  *                    ppn_send starts the server again.  (Correct, not fast: keep reads of state out of the loop.)
- *   liveness         the server leaves by itself when nothing has been published for cfg.idle_timeout_ms (default 1000): a host that
+ *   liveness         the server leaves by itself when nothing has been published for cfg.idle_timeout_ms (default 100): a host that
  *                    died leaves no kernel spinning.  A host that was merely slow loses nothing: the next ppn_send / ppn_recv finds
  *                    the server gone, re-publishes the steps it had not started and launches it again. */
 typedef struct ppn_async_config {
@@ -329,7 +331,7 @@ typedef struct ppn_async_config {
   int32_t layout;             /* observation layout as in ppn_read_observation: 0 full, 1 minimalist, 2 AC minimalist */
   int32_t as_f32;             /* rows as float32 instead of float64 */
   int32_t workgroups;         /* resident server workgroups; 0 = what the GPU holds minus one per CU (room for the policy's kernels) */
-  int32_t idle_timeout_ms;    /* 0 = 1000 */
+  int32_t idle_timeout_ms;    /* 0 = 100 */
   int32_t reserved;
   void* obs_device;           /* [batch x ppn_observation_length(layout)] rows, or NULL: no observation is written */
   size_t obs_bytes;

@@ -142,7 +142,7 @@ struct ppn_engine {
     bool server_running = false;    // the K_SERVE launch is believed to be resident (it may have left on its idle timeout)
     int layout = 0, f32 = 0, sections = 0, stride = 0;
     void* obs = nullptr; double* report_out = nullptr;
-    int n_wg = 0, n_wg_req = 0, idle_ms = 1000;
+    int n_wg = 0, n_wg_req = 0, idle_ms = 100;
     unsigned mask = 0;              // ring size - 1 (a power of two >= 2 x batch)
     unsigned long long* d_items = nullptr; unsigned* d_ctl = nullptr;
     unsigned long long* h_done = nullptr;                      // pinned: completion ring
@@ -190,6 +190,24 @@ static T* dalloc(ppn_engine* e, size_t n) {
 }
 
 #include "ppn_kernels.inc"
+
+#if defined(PPN_SPLIT_BUILD) && !defined(PPN_EMU)
+// Split build (ppn_kernel_tu.hip, __graft_entry__.build_hip): the kernel instances are compiled in translation units of their own, six
+// shares in parallel; here they are only named.
+#define PPN_EXT(W_, K_, N_) extern template __global__ void ppn_kernel<W_, K_, N_>(const KArgs);
+#define PPN_EXT_W(W_) \
+  PPN_EXT(W_, K_STEP, 0) PPN_EXT(W_, K_STEP, 1) PPN_EXT(W_, K_GAMEOVER, 0) PPN_EXT(W_, K_GAMEOVER, 1) PPN_EXT(W_, K_RESET, 0) PPN_EXT(W_, K_RESET, 1) \
+  PPN_EXT(W_, K_RUNPF, 0) PPN_EXT(W_, K_RUNPF, 1) PPN_EXT(W_, K_ROLLOUT, 0) PPN_EXT(W_, K_ROLLOUT, 1) PPN_EXT(W_, K_STEP_PERSIST, 0) PPN_EXT(W_, K_STEP_PERSIST, 1) \
+  PPN_EXT(W_, K_POLICY_ROLLOUT, 0) PPN_EXT(W_, K_POLICY_ROLLOUT, 1) PPN_EXT(W_, K_STEP_OBS, 0) PPN_EXT(W_, K_STEP_OBS, 1) PPN_EXT(W_, K_SERVE, 0) PPN_EXT(W_, K_SERVE, 1) \
+  PPN_EXT(W_, K_VALID, 0) PPN_EXT(W_, K_OBS, 0) PPN_EXT(W_, K_POLICY, 0)
+PPN_EXT_W(1) PPN_EXT_W(2) PPN_EXT_W(4)
+extern template __global__ void ppn_sched_kernel<4, 0, 64>(const KArgs);
+extern template __global__ void ppn_sched_kernel<4, 0, 256>(const KArgs);
+extern template __global__ void ppn_sched_kernel<4, 1, 64>(const KArgs);
+extern template __global__ void ppn_sched_kernel<4, 1, 256>(const KArgs);
+#undef PPN_EXT_W
+#undef PPN_EXT
+#endif
 
 // dispatch on the bitset width of the engine's kernels (-DPPN_ONLY_W1, developer builds for compiler bisection: only the one-word
 // kernels are instantiated)

@@ -1319,7 +1319,7 @@ def check_async_equals_stepping(lib_path, envname='default118', batch=8, n_steps
     order_seen = []
     while total < batch * n_steps:
         ids = b.recv(min_ready=min_ready).copy()
-        assert len(ids) >= min(min_ready, 1) and len(set(ids.tolist())) == len(ids)
+        assert len(ids) >= min(min_ready, 1) and len(set(ids.tolist())) == len(ids), (len(ids), len(set(ids.tolist())), n_recv, total, b.async_stats())
         n_recv += 1
         o_, r_ = rows(ids)
         for j, e_ in enumerate(ids):
