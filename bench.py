@@ -284,7 +284,7 @@ def async_rate(eng, case, B, steps, min_ready=256, workgroups=0, mode='noop', de
             'restarts': stats['server_restarts']}
 
 
-def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=None, split=False, max_active=None, warmup=4,
+def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=None, split=False, max_active=None, warmup=4, restart_memo=False,
                 histogram=False, lu_capacity=0, watch_capacity=0, q_plane_auto=0):
     """One of the other single-GPU configurations of BASELINE.json, timed like the headline (device-resident actions, K steps
     between synchronisations, step-kernel time from HIP events) and priced with its own SURVEY.md 8d byte count."""
@@ -299,6 +299,8 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
     if q_plane_auto:
         kw['q_plane_auto'] = 1
     eng = Engine(case, conf, batch, device=device, chronics=chronics, thermal_limits=limits, **kw)
+    if restart_memo:      # (include/ppn.h: ppn_restart_memo -- side figures only, the headline computes every restart)
+        eng.restart_memo(True)
     slots, t0 = env_assignment(0, batch, chronics)
     eng.reset(chronic_slot=slots, t0=t0)
     n_act = SPLIT_ACTION_MATRICES if split else 1
@@ -343,6 +345,12 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
            'algorithmic_bytes_per_env_step': b_step,
            'roofline_frac': (executed / float(steps)) * b_step / k_s / 1e9 / HBM_PEAK_GBS,
            'engine_capacity_flags_last_step': int((eng.read('FLAG') == 4).sum())}
+    if restart_memo:
+        ms_ = eng.restart_memo_stats()
+        out['restart_memo'] = ms_
+        out['note_restart_memo'] = ('restarts of ended episodes are computed once per chronic position and copied afterwards (bit-identical state and '
+                                    'counters: tests check_restart_memo); solves_per_step / iters_per_solve and the roofline fraction count the served '
+                                    'restarts as the solves they stand for -- read *_Msteps, not *_frac, for these entries')
     if split:
         out['illegal_fraction_last_step'] = float((eng.read('ILLEGAL') != 0).mean())
         out['q_plane_auto'] = int(q_plane_auto)
@@ -372,7 +380,8 @@ def side_config(name, envname, solver, batch, steps, device, auto_reset, limits=
 # keys of the flat `other_configs` map of the bench line, in the order other_configs() returns its entries: <key>_Msteps (M env-steps/s),
 # <key>_frac (roofline fraction on the entry's own SURVEY.md 8d byte count), <key>_kernel_ms (step kernel, HIP events)
 OTHER_CONFIG_KEYS = ['cfg1_d14_nr_b1024', 'cfg1_d14_nr_b16384', 'cfg2_d118_fdxb_b4096', 'cfg3_d118_nr_b32768',
-                     'cfg4_split_b1024_safe', 'cfg4_split_b1024_tuned', 'cfg4_split_b8192_tuned', 'cfg2_rule110_b4096']
+                     'cfg4_split_b1024_safe', 'cfg4_split_b1024_tuned', 'cfg4_split_b8192_tuned', 'cfg2_rule110_b4096',
+                     'cfg3_d118_nr_b32768_memo', 'cfg4_split_b1024_safe_memo', 'cfg4_split_b8192_tuned_memo', 'cfg2_rule110_b4096_memo']
 
 
 def search_rate(device, batch=1024, k=8, rounds=8):
@@ -439,6 +448,16 @@ def other_configs(device, auto_reset, steps):
         limits=lim, split=True, lu_capacity=3976, watch_capacity=20, q_plane_auto=1)
     add('configs[2] with the limit rule of SURVEY.md 8d config 3: limit = max(50, 1.10 x I(t = 0))', ENV_NAME, 'newton', 4096, steps,
         device, auto_reset, limits=limits_110(case118), max_active=case118.nS, histogram=True)
+    # ---- the same four with the RESTART MEMO on (ppn_restart_memo; round 6): restarts of ended episodes served from snapshots ----
+    # (40 warm-up steps: the engine's learning passes -- the first 32 steps after the memo is set up -- are behind the timed region)
+    add('cfg3 at 32768 environments, restart memo on', ENV_NAME, 'newton', 32768, max(8, steps // 3), device, auto_reset,
+        limits=lim, max_active=case118.nS, restart_memo=True, warmup=40)
+    add('configs[4] share of one GPU (batch 1024, default capacities), restart memo on', ENV_NAME, 'newton', 1024, steps, device, auto_reset,
+        limits=lim, split=True, restart_memo=True, warmup=40)
+    add('configs[4] workload at batch 8192 (capacity knobs), restart memo on', ENV_NAME, 'newton', 8192, max(8, steps // 3), device, auto_reset,
+        limits=lim, split=True, lu_capacity=3976, q_plane_auto=1, restart_memo=True, warmup=40)
+    add('configs[2] with the 110 % limit rule, restart memo on', ENV_NAME, 'newton', 4096, steps, device, auto_reset,
+        limits=limits_110(case118), max_active=case118.nS, histogram=True, restart_memo=True, warmup=40)
     return out
 
 
@@ -842,7 +861,7 @@ def main():
             try:
                 for key, mode in (('closed_loop_async_external_policy_env_steps_per_s', 'noop'),
                                   ('closed_loop_async_external_policy_reading_every_row_env_steps_per_s', 'reads_rows')):
-                    r_ = async_rate(eng, case, B, args.steps, min_ready=int(os.environ.get('PPN_BENCH_ASYNC_MIN_READY', '256')), mode=mode,
+                    r_ = async_rate(eng, case, B, args.steps, min_ready=int(os.environ.get('PPN_BENCH_ASYNC_MIN_READY', '1024')), mode=mode,
                                     device=local_rank)
                     out['config'][key] = r_['rate']
                     out['config']['closed_loop_async_server_workgroups'] = r_['workgroups']
@@ -870,7 +889,8 @@ def main():
                     flat[key + '_error'] = str(entry['error'])[:100]
                     continue
                 flat[key + '_Msteps'] = round(entry['env_steps_per_s'] / 1e6, 4)
-                flat[key + '_frac'] = round(entry['roofline_frac'], 4)
+                if not key.endswith('_memo'):      # (served restarts are counted as the solves they stand for: no roofline fraction for these)
+                    flat[key + '_frac'] = round(entry['roofline_frac'], 4)
                 flat[key + '_kernel_ms'] = round(entry['step_kernel_ms'], 4)
             try:      # topology-action search on the configs[4] engine: M simulated node-splitting candidates per second (1024 x 8)
                 flat['cfg4_search_1024x8_Mcandidates'] = round(search_rate(local_rank) / 1e6, 4)

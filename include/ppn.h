@@ -223,6 +223,21 @@ int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p);
 int ppn_set_thermal_limits(ppn_engine* e, const double* limits /* [nl] */);
 /* Upload chronic `slot` (0..n_slots-1; slots must be loaded in order). Replaces Chronic.__init__. */
 int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c);
+/* RESTART MEMO (libppn 0.3, round 6; off unless enabled here or with PPN_RESTART_MEMO=1).  Game.process_game_over of an episode that
+ * ended at chronic position (chronic, timestep) -- reset_grid, the next timestep, the cascade from the flat start, again while the
+ * restarted grid diverges too (pypownet/game.py:762-797) -- does not depend on anything else the ended episode left, except the
+ * soft-overflow counters reset_grid does not clear (survey quirk q3).  With the memo on, the first restart from a position is
+ * computed and kept (a snapshot of the environment's rows, ~18 KB on IEEE-118), every later restart from the same position of an
+ * environment whose counters are all below n_timesteps_consecutive_soft_overflow_breaks copies it; the cumulative solve / iteration
+ * counters (PPN_F_N_SOLVES, PPN_F_N_ITERS) and the epoch move by what the computed restart added, so every field reads as if the
+ * restart had been computed (tests: check_restart_memo, bit for bit against an engine without it, and the oracle lock-steps run
+ * with PPN_RESTART_MEMO=1).  Served where ppn_step restarts with auto_reset = 2 (the deferred restart); not used with
+ * PPN_LOOP_RANDOM.  max_bytes: memory the snapshots may take (<= 0: 1 GiB); snapshots are dropped when chronics or thermal limits
+ * change.  bench.py's headline keeps it OFF: every restart of the timed region is a computed one, as the reference's is. */
+int ppn_restart_memo(ppn_engine* e, int32_t enable, int64_t max_bytes);
+/* 0 snapshots held, 1 restarts served from a snapshot, 2 restarts that were not eligible (a soft-overflow counter at its threshold),
+ * 3 snapshot capacity, 4 bytes per snapshot; -1 when the memo is off */
+int64_t ppn_restart_memo_stat(ppn_engine* e, int32_t which);
 
 /* ---- game ---------------------------------------------------------------------------------------- */
 /* Game.__init__ tail for the listed environments (env_ids NULL = all): initial topology, case voltages,
@@ -298,8 +313,9 @@ int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int3
  *
  *     ppn_async_start(e, &cfg);                         a step server becomes resident on the GPU
  *     ppn_send(e, all_env_ids, batch, actions, ...);    every environment gets its first action
- *     loop:  ppn_recv(e, min_ready, ...) -> the ids of >= min_ready environments whose step is complete (their observation rows and
- *                                            report rows are in the caller's device buffers); stragglers keep running
+ *     loop:  ppn_recv(e, min_ready, ...) -> the ids of >= min_ready environments whose step is complete (their report rows are in the
+ *                                            caller's device buffer, their observation rows are being gathered on the session's
+ *                                            stream); stragglers keep running
  *            policy(observation rows of those ids) -> actions
  *            ppn_send(e, those ids, n, actions, ...)
  *     ppn_async_stop(e);
@@ -309,9 +325,11 @@ int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int3
  *   step semantics   Game.step with the fused restart (auto_reset = 1): the observation row of an environment whose episode ended
  *                    shows the restarted episode, its report row (done, flag, reward sum) the step that ended it -- what an agent
  *                    behind RunEnv.step / process_game_over sees (runner.py:81-96).
- *   ownership        obs_device / report_device are DEVICE buffers of the caller, [batch x row]: row `env` is rewritten by every
- *                    step of environment `env`, and is stable from the ppn_recv that returned `env` until the ppn_send that sends it
- *                    again.  An environment may be in flight once: sending it again before it was received is PPN_E_STATE.
+ *   ownership        obs_device / report_device are DEVICE buffers of the caller, [batch x row]: report row `env` is rewritten by
+ *                    every step of environment `env`; observation row `env` is written by a gather kernel that the ppn_recv which
+ *                    returns `env` queues on ppn_async_stream(e) -- complete for everything queued on that stream afterwards (the
+ *                    policy), a reader elsewhere synchronises with that stream first.  Both are stable until the ppn_send that
+ *                    sends `env` again.  An environment may be in flight once: sending it again before it was received is PPN_E_STATE.
  *   streams          the server runs on a stream of its own; ppn_send's work is queued on ppn_async_stream(e) (a non-blocking HIP
  *                    stream): device-side action / id buffers handed to ppn_send must be complete ON THAT STREAM (run the policy
  *                    on it, or make it wait for the policy's event) and must stay untouched until the enqueue kernel has read
@@ -330,7 +348,7 @@ typedef struct ppn_async_config {
   int32_t struct_size;        /* = sizeof(ppn_async_config) */
   int32_t layout;             /* observation layout as in ppn_read_observation: 0 full, 1 minimalist, 2 AC minimalist */
   int32_t as_f32;             /* rows as float32 instead of float64 */
-  int32_t workgroups;         /* resident server workgroups; 0 = what the GPU holds minus one per CU (room for the policy's kernels) */
+  int32_t workgroups;         /* resident server workgroups; 0 = four per CU (every SIMD keeps half its registers: room for the policy's multi-wave kernels) */
   int32_t idle_timeout_ms;    /* 0 = 100 */
   int32_t reserved;
   void* obs_device;           /* [batch x ppn_observation_length(layout)] rows, or NULL: no observation is written */

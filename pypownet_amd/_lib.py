@@ -90,7 +90,7 @@ EXPORTS = ['ppn_create', 'ppn_destroy', 'ppn_last_error', 'ppn_set_thermal_limit
            'ppn_read', 'ppn_write', 'ppn_sync', 'ppn_stream', 'ppn_kernel_time', 'ppn_dim', 'ppn_version', 'ppn_set_reward',
            'ppn_simulate_candidates', 'ppn_read_observation', 'ppn_observation_length', 'ppn_wait', 'ppn_runpf_arrays', 'ppn_rollout',
            'ppn_policy_actions', 'ppn_rollout_policy', 'ppn_step_observe', 'ppn_async_start', 'ppn_send', 'ppn_recv', 'ppn_async_stop',
-           'ppn_async_stream', 'ppn_async_stat']
+           'ppn_async_stream', 'ppn_async_stat', 'ppn_restart_memo', 'ppn_restart_memo_stat']
 
 
 def _preload_torch_hip_runtime():
@@ -199,6 +199,10 @@ def bind_signatures(lib, full_abi=True):
         lib.ppn_async_stream.restype = vp
         lib.ppn_async_stat.argtypes = [vp, C.c_int32]
         lib.ppn_async_stat.restype = C.c_int64
+        lib.ppn_restart_memo.argtypes = [vp, C.c_int32, C.c_int64]
+        lib.ppn_restart_memo.restype = C.c_int
+        lib.ppn_restart_memo_stat.argtypes = [vp, C.c_int32]
+        lib.ppn_restart_memo_stat.restype = C.c_int64
     lib.ppn_stream.argtypes = [vp]
     lib.ppn_stream.restype = vp
     lib.ppn_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -246,6 +246,26 @@ struct DevRules {
   double rw[13];     // ppn_reward_params, in declaration order
 };
 
+// RESTART MEMO (round 6, include/ppn.h: ppn_restart_memo; off unless asked for).  process_game_over of an episode that ended at
+// chronic position (slot, row) -- reset_grid, the next timestep, the cascade from the flat start, repeated while the restarted grid
+// diverges as well (game.py:762-797) -- is a function of that position alone, with one exception: reset_grid does not clear the
+// soft-overflow counters (quirk q3), which decide cuts for lines whose counter has reached n_soft_consecutive and are incremented for
+// the lines still overflowed at the end.  So for an environment that ends with every counter BELOW the threshold the restarted
+// state is f(slot, row), up to counter[l] = overflowed_after[l] ? counter[l] + 1 : 0 -- and the engine may keep it: `index[key]`
+// names the snapshot (a packed row of `stride` bytes in `blob`: memo_xfer, ppn_game.inc) of key = c_off[slot] + slot + row + 1, or
+// -1.  The first restart from a position computes and saves, the later ones copy 18 KB instead of running ~6 Newton iterations;
+// solve / iteration / epoch counters move by what the computed restart added (meta).  Not used with random chronic looping.
+struct DevMemo {
+  int* index;        // [n_keys] snapshot number, -1 none, -2 being written
+  int* count;        // [1] snapshots handed out
+  int cap, n_keys;
+  unsigned char* blob;
+  size_t stride;
+  int* meta;         // [cap x 4] solves, iterations, epochs the computed restart added; spare
+  int* tmp;          // [batch x 8] key (-1: not eligible) and counters of an environment at the moment its restart began
+  int* stats;        // [4] restarts served from a snapshot (apply kernel), snapshots saved, restarts not eligible, spare
+};
+
 // Static (shared by all environments) + chronic tensors.  All pointers are device pointers.
 struct DevCase {
   int nS, nP, nL, nl, nrows, ntopo, alen, obslen;

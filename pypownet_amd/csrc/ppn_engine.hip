@@ -144,7 +144,7 @@ struct ppn_engine {
     void* obs = nullptr; double* report_out = nullptr;
     int n_wg = 0, n_wg_req = 0, idle_ms = 100;
     unsigned mask = 0;              // ring size - 1 (a power of two >= 2 x batch)
-    unsigned long long* d_items = nullptr; unsigned* d_ctl = nullptr;
+    unsigned long long* d_items = nullptr; unsigned* d_ctl = nullptr; int* d_rids = nullptr;      // d_rids: [batch] ids of the last receive (rows of its observation gather)
     unsigned long long* h_done = nullptr;                      // pinned: completion ring
     int *h_ids = nullptr, *h_out = nullptr; u8* h_acts = nullptr;      // pinned: ids / action rows of sends, ids of receives
     unsigned long long published = 0;   // items pushed into the ring since the session began (re-publications included)
@@ -156,10 +156,13 @@ struct ppn_engine {
     hipStream_t s_server = 0, s_async = 0;
   } as;
   hipStream_t launch_stream = 0;  // (launch_w: the stream of the launch in flight when it is not `stream`)
+  bool memo_on = false; size_t memo_max_bytes = (size_t)1 << 30; std::vector<void*> memo_allocs; DevMemo memo_h; const DevMemo* d_memo = nullptr; int memo_learn_left = 0, memo_learn_every = 16; long memo_tick = 0;      // (memo_h: host copy of *d_memo)
+       // restart memo (DevMemo; ppn_restart_memo)
   int last_step_form = 0;     // ppn_dim(19): kernel form of the last step launch (0 K_STEP, 1 K_STEP_PERSIST, 2 K_STEP_OBS, 3 K_ROLLOUT; + 4: two-capacity stepping)
 };
 
 static std::string g_create_error;
+static int memo_setup(ppn_engine* e);
 
 static int fail(ppn_engine* e, int code, const char* fmt, ...) {
   char buf[512];
@@ -266,7 +269,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
       body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, a.restart_prio, env, 0, a.cap_class);
       if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0);
     }
-    else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0);
+    else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0, a.memo);
     else if (KIND == K_RESET) body_reset<W, NT>(a.d, a.st, S, a.ids, a.slots, a.t0, env, 0);
     else if (KIND == K_RUNPF) body_runpf<W, NT>(a.d, a.st, S, env, 0);
     else if (KIND == K_VALID) body_valid(a.d, a.st, S, a.actions, a.valid, env, 0);
@@ -467,6 +470,8 @@ static void free_all(ppn_engine* e) {
   for (void* p : e->allocs) dev_free(p);
   for (void* p : e->chronic_allocs) dev_free(p);
   for (void* p : e->cand_allocs) dev_free(p);
+  for (void* p : e->memo_allocs) dev_free(p);
+  e->memo_allocs.clear();
   e->allocs.clear(); e->chronic_allocs.clear(); e->cand_allocs.clear();
 #ifndef PPN_EMU
   for (auto ev : e->ev) (void)hipEventDestroy(ev);
@@ -922,6 +927,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
     e->lds_sched = ppn_carve_sched(d, e->W, nullptr, &tmp); }
   { const char* v = getenv("PPN_SCHED_PREPASS"); if (v) { const int k = atoi(v); e->sched_prepass = (k == 0) ? 0 : (k == 64 || k == 256 ? 2 : 1); if (k == 256) e->sched_threads = 256; } }
   { const char* v = getenv("PPN_TWO_CAP"); if (v && v[0] == '0') e->two_cap_allowed = false; }
+  { const char* v = getenv("PPN_RESTART_MEMO"); if (v && v[0] != '0') { e->memo_on = true; if (atol(v) > 1) e->memo_max_bytes = (size_t)atol(v); } }      // (ppn_restart_memo; tests run whole suites with it on)
   { const char* v = getenv("PPN_TWO_CAP_ECAP"); if (v) e->two_cap_forced = atoi(v); }
   { const char* v = getenv("PPN_SCHED_PREPASS_ROUNDS"); if (v && atoi(v) > 0) e->sched_rounds = atoi(v); }
   if (e->lds_bytes > 160 * 1024) {
@@ -961,7 +967,29 @@ extern "C" int ppn_set_thermal_limits(ppn_engine* e, const double* limits) {
   enter(e);
   PPN_QUIESCE(e);
   if (!e || !limits) return PPN_E_INVALID;
-  return dev_h2d((void*)e->dc.limits, limits, sizeof(double) * e->dc.nl, e->stream) ? fail(e, PPN_E_HIP, "limits upload failed") : PPN_OK;
+  if (dev_h2d((void*)e->dc.limits, limits, sizeof(double) * e->dc.nl, e->stream)) return fail(e, PPN_E_HIP, "limits upload failed");
+  return e->chronics_dirty ? PPN_OK : memo_setup(e);      // (snapshots of restarts under the old limits are void)
+}
+
+extern "C" int ppn_restart_memo(ppn_engine* e, int32_t enable, int64_t max_bytes) {
+  enter(e);
+  PPN_QUIESCE(e);
+  if (!e) return PPN_E_INVALID;
+  e->memo_on = enable != 0;
+  if (max_bytes > 0) e->memo_max_bytes = (size_t)max_bytes;
+  return e->chronics_dirty ? PPN_OK : memo_setup(e);      // (sync_chronics builds it with the tables it keys on)
+}
+extern "C" int64_t ppn_restart_memo_stat(ppn_engine* e, int32_t which) {
+  if (!e || !e->d_memo) return which == 3 ? 0 : -1;
+  if (which == 3) return e->memo_h.cap;
+  if (which == 4) return (int64_t)e->memo_h.stride;
+  int v[4] = {0, 0, 0, 0};
+#ifndef PPN_EMU
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+#endif
+  if (which == 0) { if (dev_d2h(v, e->memo_h.count, sizeof(int), e->stream)) return -1; return std::min(v[0], e->memo_h.cap); }
+  if (dev_d2h(v, e->memo_h.stats, sizeof v, e->stream)) return -1;
+  return which == 1 ? v[0] : (which == 2 ? v[2] : -1);
 }
 
 extern "C" int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c) {
@@ -1121,9 +1149,63 @@ static int sync_chronics(ppn_engine* e) {
   d.c_roll2 = upload(e, roll2, e->chronic_allocs);
   if (e->mem_failed) { e->mem_failed = false; return fail(e, PPN_E_HIP, "chronic upload failed: %s", dev_err()); }
   e->chronics_dirty = false;
+  { const int rcm = memo_setup(e); if (rcm) return rcm; }
   return size_q_plane(e);
 }
 
+// Restart memo: (re)built empty whenever the chronics change (the keys are chronic positions) or it is switched on.
+static void memo_release(ppn_engine* e) {
+#ifndef PPN_EMU
+  if (!e->memo_allocs.empty()) (void)hipStreamSynchronize(e->stream);
+#endif
+  for (void* p : e->memo_allocs) dev_free(p);
+  e->memo_allocs.clear();
+  e->d_memo = nullptr; memset(&e->memo_h, 0, sizeof e->memo_h);
+}
+static int memo_setup(ppn_engine* e) {
+  memo_release(e);
+  if (!e->memo_on || e->dc.R.loop_mode == PPN_LOOP_RANDOM || e->chronics.empty()) return PPN_OK;
+  DevMemo& M = e->memo_h;
+  long keys = 0;
+  for (const auto& c : e->chronics) keys += (long)c.T + 1;
+  const size_t stride = ppn_memo_stride(e->dc);
+  long cap = std::min<long>(keys, (long)(e->memo_max_bytes / stride));
+  if (cap < 1) return PPN_OK;
+  auto grab = [&](size_t bytes, int fill) -> void* {
+    void* p = nullptr;
+    if (dev_malloc(&p, bytes + 16)) return nullptr;
+    e->memo_allocs.push_back(p);
+    std::vector<unsigned char> h(bytes, (unsigned char)fill);
+    if (dev_h2d(p, h.data(), bytes, e->stream)) return nullptr;
+#ifndef PPN_EMU
+    (void)hipStreamSynchronize(e->stream);      // (the staging vector dies here)
+#endif
+    return p;
+  };
+  void* index = grab(sizeof(int) * (size_t)keys, 0xFF);
+  void* count = grab(64, 0);
+  void* meta = grab(sizeof(int) * 4 * (size_t)cap, 0);
+  void* tmp = grab(sizeof(int) * 8 * (size_t)e->batch, 0xFF);
+  void* stats = grab(64, 0);
+  void* blob = nullptr;
+  if (index && count && meta && tmp && stats && !dev_malloc(&blob, stride * (size_t)cap + 16)) e->memo_allocs.push_back(blob);
+  if (!blob) { memo_release(e); return fail(e, PPN_E_HIP, "restart memo: device allocation failed (%ld snapshots of %zu bytes)", cap, stride); }
+  M.index = (int*)index; M.count = (int*)count; M.cap = (int)cap; M.n_keys = (int)keys; M.blob = (unsigned char*)blob; M.stride = stride;
+  M.meta = (int*)meta; M.tmp = (int*)tmp; M.stats = (int*)stats;
+  void* dm = nullptr;
+  if (dev_malloc(&dm, sizeof(DevMemo) + 16)) { memo_release(e); return fail(e, PPN_E_HIP, "restart memo: device allocation failed"); }
+  e->memo_allocs.push_back(dm);
+  const DevMemo mh = M;      // (memo_release clears memo_h)
+  if (dev_h2d(dm, &mh, sizeof(DevMemo), e->stream)) { memo_release(e); return fail(e, PPN_E_HIP, "restart memo: upload failed"); }
+#ifndef PPN_EMU
+  (void)hipStreamSynchronize(e->stream);
+#endif
+  e->d_memo = (const DevMemo*)dm;
+  e->memo_learn_left = 32; e->memo_tick = 0;
+  { const char* v = getenv("PPN_MEMO_LEARN_STEPS"); if (v) e->memo_learn_left = atoi(v); }
+  { const char* v = getenv("PPN_MEMO_LEARN_EVERY"); if (v) e->memo_learn_every = atoi(v); }
+  return PPN_OK;
+}
 static KArgs make_args(ppn_engine* e, bool sim_state) {
   KArgs a;
   memset(&a, 0, sizeof a);
@@ -1131,6 +1213,7 @@ static KArgs make_args(ppn_engine* e, bool sim_state) {
   a.st = sim_state ? e->sim : e->st;
   a.n_steps = 1;
   a.cap_class = -1;
+  a.memo = sim_state ? nullptr : e->d_memo;
   return a;
 }
 
@@ -1430,6 +1513,26 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
   }
   const int mode = simulate ? 0 : (auto_reset == 2 ? 2 : (auto_reset ? 1 : 0));
   if (mode != 2) { int rcs = settle_restarts(e); if (rcs) return rcs; }
+  else if (e->d_memo && e->pending_restart) {
+    // restart memo, in front of the step kernel: (1) the owed restarts that have a snapshot are served by a light kernel; (2) a
+    // LEARNING pass of the game-over kernel computes and saves the eligible ones that have none yet (body_game_over, only_owed = 2) --
+    // run in the first steps after the memo was set up and every n-th step afterwards (positions that come up rarely): it is carved
+    // for the solver and costs a launch of `batch` such workgroups even when it finds nothing to do.  Whatever neither takes is
+    // restarted by the step kernel itself, as without the memo.
+    KArgs am = make_args(e, false);
+#ifdef PPN_EMU
+    for (int env = 0; env < e->batch; ++env) (void)body_memo_apply(am.d, am.st, am.memo, env, 0);
+#else
+    hipLaunchKernelGGL(ppn_memo_apply_kernel, dim3(e->batch), dim3(64), 0, e->stream, am);
+    if (hipGetLastError() != hipSuccess) return fail(e, PPN_E_HIP, "restart-memo launch failed: %s", dev_err());
+#endif
+    const bool learn = e->memo_learn_left > 0 || (e->memo_learn_every > 0 && (++e->memo_tick % e->memo_learn_every) == 0);
+    if (e->memo_learn_left > 0) --e->memo_learn_left;
+    if (learn) {
+      am.sim = 2;
+      if (launch<K_GAMEOVER>(e, am, e->batch)) return fail(e, PPN_E_HIP, "restart-memo pass launch failed: %s", dev_err());
+    }
+  }
   if (simulate) { if (copy_state(e, &e->sim, &e->st)) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err()); }
   KArgs a = make_args(e, simulate != 0);
   a.actions = dact; a.sim = simulate ? 1 : 0; a.auto_reset = mode;

@@ -23,8 +23,11 @@
 #include "ppn_obs.inc"
 #include "ppn_kernels.inc"
 
-#if !defined(PPN_TU_W) || !defined(PPN_TU_NT)
-#error "compile with -DPPN_TU_W=1|2|4 -DPPN_TU_NT=0|1"
+#if !defined(PPN_TU_W) || !defined(PPN_TU_NT)      // (a bare `hipcc -c` of this file compiles the first share)
+#undef PPN_TU_W
+#undef PPN_TU_NT
+#define PPN_TU_W 1
+#define PPN_TU_NT 0
 #endif
 
 #define PPN_INST(K) template __global__ void ppn_kernel<PPN_TU_W, K, PPN_TU_NT>(const KArgs);

@@ -289,6 +289,15 @@ class Engine(object):
         return dict(in_flight=int(self._lib.ppn_async_stat(self._h, 0)), workgroups=int(self._lib.ppn_async_stat(self._h, 1)),
                     server_restarts=int(self._lib.ppn_async_stat(self._h, 2)), republished=int(self._lib.ppn_async_stat(self._h, 3)))
 
+    def restart_memo(self, enable=True, max_bytes=0):
+        """Restart memo (include/ppn.h: ppn_restart_memo): restarts of ended episodes are computed once per chronic position and
+        copied afterwards -- same fields, counters included, as if every restart had been computed."""
+        self._check(self._lib.ppn_restart_memo(self._h, 1 if enable else 0, int(max_bytes)), 'ppn_restart_memo')
+
+    def restart_memo_stats(self):
+        g = lambda k: int(self._lib.ppn_restart_memo_stat(self._h, k))      # noqa: E731
+        return dict(snapshots=g(0), served=g(1), not_eligible=g(2), capacity=g(3), bytes_per_snapshot=g(4))
+
     def simulate(self, actions):
         a = self._actions(actions)
         self._check(self._lib.ppn_step(self._h, a.ctypes.data, 0, 1, 0), 'ppn_step(simulate)')

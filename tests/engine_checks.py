@@ -958,6 +958,68 @@ STATE_FIELDS = ('VM', 'VA', 'PG', 'QG', 'VG', 'PD', 'QD', 'PF', 'QF', 'PT', 'QT'
                 'ILLEGAL_COUNTS', 'ACTION_SWITCHES', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'N_STEPS', 'DEAD')
 
 
+def check_restart_memo(lib_path, envname='default118', steps=40, batch=64, limits_file='bench_limits.json', max_active_buses=118, seed=11,
+                       random_acts=False, solver='newton', hard=False, look_every=5, oracle=True, max_bytes=0, start_spread=5):
+    """Restart memo (include/ppn.h: ppn_restart_memo): an engine that keeps the restarted state of every chronic position it has
+    computed once and copies it afterwards, against an engine that computes every restart -- ppn_step(auto_reset = 2), the same
+    actions: the report fields after every step and, whenever the state is looked at, EVERY state field bit for bit, cumulative solve
+    and Newton-iteration counts and the epoch included (a served restart moves them by what the computed one added).  `oracle`:
+    flags, chronic positions and the solve / iteration counts also against the C oracle, which knows nothing of any memo."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    conf = {'solver': solver} if solver != 'dc' else {'loadflow_mode': 'DC'}
+    if hard:
+        conf['game_over_mode'] = 'hard'
+    case, cfg, chronics = load_env(envname, conf=conf)
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    kw = {}
+    if limits_file:
+        with open(os.path.join(ENVS, envname, limits_file)) as f:
+            kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
+    ekw = dict(kw)
+    if max_active_buses:
+        ekw['max_active_buses'] = max_active_buses
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **ekw)      # every restart computed
+    b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **ekw)      # restart memo
+    b.restart_memo(True, max_bytes=max_bytes)
+    engines = [a, b]
+    if oracle:
+        engines.append(engine_with_library(ORACLE_LIB, case, cfg, batch, chronics=chronics, **kw))
+    slots, t0 = default_assignment(np.arange(batch) * start_spread, chronics)
+    for e in engines:
+        e.reset(chronic_slot=slots, t0=t0)
+    rng = np.random.default_rng(seed)
+    report = ('DONE', 'FLAG', 'ILLEGAL', 'REWARD', 'CASCADE_DEPTH', 'LINE_EVENTS', 'SOLVE_OUTCOME', 'ILLEGAL_COUNTS', 'ACTION_SWITCHES', 'STEP_REPORT')
+    n_done = 0
+    for t in range(steps):
+        acts = random_actions(case, rng, batch) if random_acts else np.zeros((batch, case.action_length), dtype=np.uint8)
+        a.step(acts, auto_reset=2)
+        b.step(acts, auto_reset=2)
+        if oracle:
+            engines[2].step(acts, auto_reset=True)
+        for f in report:       # (reading these does not settle the owed restarts)
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
+        n_done += int(a.read('DONE').sum())
+        if t % look_every == look_every - 1 or t == steps - 1:      # look at the state (this settles the owed restarts: apply, then compute the rest)
+            for f in STATE_FIELDS + ('EPOCH', 'RETURN', 'BUS_TYPE'):
+                assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f, np.nonzero((a.read(f) != b.read(f)).reshape(batch, -1).any(axis=1))[0][:8])
+            assert np.array_equal(a.observations(), b.observations(), equal_nan=True)
+            if oracle:
+                o = engines[2]
+                # (under node splitting a solve may take one iteration more or less than the oracle's -- another elimination order, another
+                #  rounding: the counts are compared on the unsplit grid only, like check_random_actions_vs_c_oracle)
+                for f in ('DONE', 'FLAG', 'CHRONIC_ROW', 'CHRONIC_SLOT', 'LINES_STATUS', 'SOFT_COUNT') + (() if random_acts else ('N_SOLVES', 'N_ITERS')):
+                    assert np.array_equal(b.read(f), o.read(f)), (t, f)
+    st = b.restart_memo_stats()
+    assert a.restart_memo_stats()['capacity'] == 0
+    for e in engines:
+        e.close()
+    st['episodes_ended'] = n_done
+    return st
+
+
 def check_rollout_equals_steps(lib_path, envname='default118', batch=24, n_steps=9, bench_limits=True, random_acts=False, seed=5,
                                modes=(1, 2, 0)):
     """ppn_rollout (n_steps Game.step calls per environment in one launch, every environment running ahead on its own) leaves
@@ -1285,6 +1347,8 @@ def check_async_equals_stepping(lib_path, envname='default118', batch=8, n_steps
         obs_ptr, rep_ptr, obs_bytes = obs_t.data_ptr(), rep_t.data_ptr(), obs_t.numel() * obs_t.element_size()
 
         def rows(ids):
+            # (the observation rows of a receive are gathered ON THE SESSION'S STREAM, include/ppn.h: a reader on another stream waits for it)
+            torch.cuda.ExternalStream(b.async_stream_ptr()).synchronize()
             ix = torch.as_tensor(np.asarray(ids, dtype=np.int64), device='cuda')
             return obs_t[ix].cpu().numpy(), rep_t[ix].cpu().numpy()
     else:

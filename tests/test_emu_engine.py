@@ -137,6 +137,23 @@ def test_emu_deferred_restart_equals_fused(emu_lib):
                                      random_acts=True) > 0
 
 
+@pytest.mark.parametrize('kw', [
+    dict(steps=30, batch=10, limits_file='bench_limits_110.json'),                                  # the 110 % limit rule: most steps end the episode, restarts after restarts
+    dict(steps=24, batch=8),                                                                        # the bench workload's limits
+    dict(steps=24, batch=8, random_acts=True, max_active_buses=0),                                  # node splitting: four-word kernels, schedules of their own
+    dict(steps=30, batch=8, limits_file='bench_limits_110.json', solver='fdxb', hard=True),         # the reference's solver, hard game-over mode (next chronic)
+    dict(envname='default14_for_tests_alpha', steps=60, batch=8, limits_file=None, max_active_buses=0, random_acts=True, oracle=False),
+    dict(steps=30, batch=10, limits_file='bench_limits_110.json', max_bytes=3 * 20000),             # a memo that holds three snapshots: the rest is computed
+])
+def test_emu_restart_memo(emu_lib, kw):
+    """ppn_restart_memo: restarts served from snapshots leave every field as the computed restart does."""
+    st = ec.check_restart_memo(emu_lib, **kw)
+    assert st['episodes_ended'] > 0 and st['snapshots'] > 0, st
+    if kw.get('limits_file') == 'bench_limits_110.json' and not kw.get('max_bytes'):
+        assert st['served'] > 0, st
+    print(kw, st)
+
+
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_emu_repacked_schedule(emu_lib, solver):
     """Pivots and Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle."""

@@ -85,6 +85,34 @@ def test_gpu_full_size_default118_4096_bench_workload():
     assert st['done'] > 4096 and st['solves'] > 4096 * 60
 
 
+@pytest.mark.parametrize('kw', [
+    dict(steps=40, batch=2048),                                                                      # the bench workload (two-word Newton kernels), C oracle beside it
+    dict(steps=24, batch=1024, limits_file='bench_limits_110.json'),                                 # the 110 % limit rule: restarts after restarts
+    dict(steps=24, batch=768, random_acts=True, max_active_buses=0),                                 # node splitting: four-word kernels, two-capacity stepping
+    dict(steps=24, batch=512, limits_file='bench_limits_110.json', solver='fdxb', hard=True),        # the reference's solver, hard game-over mode
+    dict(envname='default14_for_tests_alpha', steps=80, batch=256, limits_file=None, max_active_buses=0, random_acts=True, oracle=False),
+    dict(steps=24, batch=1024, limits_file='bench_limits_110.json', max_bytes=40 * 20000),           # a memo that fills up
+])
+def test_gpu_restart_memo(kw):
+    """ppn_restart_memo (round 6): restarts of ended episodes served from snapshots -- one per chronic position, taken from the first
+    computed restart -- leave every field, cumulative solve / Newton-iteration counts and epochs included, bit for bit what an
+    engine that computes every restart shows, and what the C oracle (which knows no memo) counts."""
+    st = ec.check_restart_memo(HIP, **kw)
+    assert st['episodes_ended'] > 0 and st['snapshots'] > 0 and st['served'] > 0, st
+
+
+def test_gpu_full_size_bench_workload_with_restart_memo():
+    """The 4096 x 60 lock-step of the headline workload against the C oracle with the memo on (PPN_RESTART_MEMO=1): flags, line
+    status, counters, chronic positions, cumulative solves and Newton iterations bit-exact, voltages <= 1e-8 -- served restarts
+    included (deferred restart, as bench.py steps)."""
+    os.environ['PPN_RESTART_MEMO'] = '1'
+    try:
+        st = ec.check_full_size_lockstep(HIP, 'default118', 4096, 60, 20, bench_limits=True, max_active_buses=118, auto_reset=2)
+    finally:
+        os.environ.pop('PPN_RESTART_MEMO', None)
+    assert st['done'] > 4096 and st['solves'] > 4096 * 60
+
+
 @pytest.mark.parametrize('auto_reset', [True, 2])
 def test_gpu_full_size_default118_4096_limit_rule_110(auto_reset):
     """configs[2] under the limit rule SURVEY.md 8d wrote down for it -- limit = max(50, 1.10 x I(t = 0)) -- at the

@@ -33,10 +33,29 @@ def run(variant, B, K):
     acts_h = np.zeros((B, case.action_length), dtype=np.uint8)
     torch.cuda.synchronize()
     eng.sync()
+    if os.environ.get('PPN_ASYNC_ANATOMY'):
+        zero = np.zeros((B, 32), dtype=np.int64)
+        eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
+        anat0 = (eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum())
     if 'rollout' in variant:      # reference point: the device-policy rollout kernel (no host in the loop, no observation)
         eng.rollout_policy('do_nothing', [], 3); eng.sync()
         t_ = time.perf_counter(); eng.rollout_policy('do_nothing', [], K); eng.sync()
         print('%-16s B=%d K=%d: %.3f M env-steps/s (ppn_rollout_policy, do-nothing)' % (variant, B, K, B * K / (time.perf_counter() - t_) / 1e6), flush=True)
+        if os.environ.get('PPN_ASYNC_ANATOMY'):
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from profile_phases import NAMES
+            out = np.zeros((B, 32), dtype=np.int64)
+            eng._check(eng._lib.ppn_read(eng._h, 100, out.ctypes.data, out.nbytes, 1, 0), 'read prof')
+            tot = out.sum(axis=0).astype(np.float64)
+            n = float(B * (K + 3))
+            nsolve = float(eng.read('N_SOLVES').sum() - anat0[0]); nit = float(eng.read('N_ITERS').sum() - anat0[1])
+            print('    solves %d iterations %d (%.2f / %.2f per step); shader cycles:' % (nsolve, nit, nsolve / n, nit / n))
+            for k, name in enumerate(NAMES):
+                if k == 13:
+                    continue
+                unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
+                print('      %-44s %8.0f cyc per %s' % (name, tot[k] / {'iteration': nit, 'env-step': n, 'solve': nsolve}[unit], unit))
+            print('      %-44s %8.0f cyc and %.1f us per env-step' % ('step body', tot[14] / n, tot[15] / n * 1e-2))
         eng.close()
         return
     wg = [int(v[2:]) for v in variant.split('+') if v.startswith('wg')]
@@ -74,6 +93,26 @@ def run(variant, B, K):
     el = time.perf_counter() - t_begin
     s = eng.async_stats()
     eng.async_stop()
+    if os.environ.get('PPN_ASYNC_ANATOMY'):      # (a -DPPN_PROF library: K_SERVE books 100 MHz ticks per served step into the profile rows)
+        import ctypes as C
+        out = np.zeros((B, 32), dtype=np.int64)
+        eng._check(eng._lib.ppn_read(eng._h, 100, out.ctypes.data, out.nbytes, 1, 0), 'read prof')
+        n = max(float(out[:, 27].sum()), 1.0)
+        print('    served steps %d: per step  waiting for an item %.1f us | acquire + body_step %.1f us | observation + report %.1f us | release + record %.1f us'
+              % (n, out[:, 23].sum() / n * 1e-2, out[:, 24].sum() / n * 1e-2, out[:, 25].sum() / n * 1e-2, out[:, 26].sum() / n * 1e-2), flush=True)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from profile_phases import NAMES
+        tot = out.sum(axis=0).astype(np.float64)
+        nsolve = float(eng.read('N_SOLVES').sum() - anat0[0]); nit = float(eng.read('N_ITERS').sum() - anat0[1])
+        print('    solves %d iterations %d (%.2f / %.2f per step); shader cycles:' % (nsolve, nit, nsolve / n, nit / n))
+        for k, name in enumerate(NAMES):
+            if k == 13:
+                continue
+            unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
+            print('      %-44s %8.0f cyc per %s' % (name, tot[k] / {'iteration': nit, 'env-step': n, 'solve': nsolve}[unit], unit))
+        print('      %-44s %8.0f cyc and %.1f us per env-step' % ('step body', tot[14] / n, tot[15] / n * 1e-2))
+        busy = (out[:, 24].sum() + out[:, 25].sum() + out[:, 26].sum()) * 1e-8
+        print('    workgroup-seconds busy %.4f over %.4f s of session -> %.0f workgroups busy on average' % (busy, el, busy / el), flush=True)
     tf = time.perf_counter()
     a = np.array([(x[1], x[2], x[3]) for x in stamps])
     worst = sorted(stamps, key=lambda x: -x[1])[:4]
