@@ -23,7 +23,8 @@ cd $ROOT
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats_all -o bench_all --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-rollout > $OUT/bench_all_under_rocprof.log 2>&1
 cd $ROOT
-PPN_REBUILD=1 python tools/profile_phases.py 4096 10 > $OUT/phase_profile_b4096.txt 2>&1
+# (build/libppn_prof.so is built in the development container: python __graft_entry__.py variant prof -DPPN_PROF -- build/ travels)
+python tools/profile_phases.py 4096 10 > $OUT/phase_profile_b4096.txt 2>&1
 PPN_PROF_ENV=default14 python tools/profile_phases.py 1024 20 > $OUT/phase_profile_default14_b1024.txt 2>&1
 PPN_PROF_ENV=default14 python tools/profile_phases.py 16384 10 > $OUT/phase_profile_default14_b16384.txt 2>&1
 python tools/profile_phases.py 1024 8 split > $OUT/phase_profile_split_b1024.txt 2>&1
@@ -56,3 +57,9 @@ tail -n 2 $OUT/soak_random_w4_newton.txt $OUT/soak_random_w4_fdxb.txt $OUT/soak_
 python tests/tools/chain_lengths.py 2>&1 | grep -v Warn > $OUT/chain_lengths.txt
 for pad in 0 3500 9000 17000 30000; do echo "PPN_LDS_PAD=$pad: $(PPN_LDS_PAD=$pad python tests/tools/lib_compare.py default118 newton 4096 60 default 2>/dev/null | tail -1)"; done > $OUT/occupancy_sweep.txt
 python tools/profile_phases.py 256 10 > $OUT/phase_profile_b256_one_env_per_cu.txt 2>&1
+# ---- round 6 extras ------------------------------------------------------------------------------------------------------------
+# asynchronous session (ppn_send / ppn_recv): rates for server sizes / min_ready, and the anatomy of a served step (profiling build)
+python tools/async_rate.py 4096 60 256,1024,2048 0,1536 2>&1 | grep -v amdgpu.ids > $OUT/async_rate.txt
+PPN_ASYNC_ANATOMY=1 PPN_DEBUG_LIB=build/libppn_prof.so python tools/dev/async_debug.py 4096 40 devact+idsdev+mr1024 rollout 2>&1 | grep -v amdgpu.ids > $OUT/async_anatomy.txt
+python tools/search_rate.py > $OUT/search_rate.txt 2>&1
+# the 100k-solve random-action soak of the -m gpu suite is the short form of the two soaks above
