@@ -879,6 +879,38 @@ def main():
                 eng.read('DONE'); eng.read('FLAG'); eng.read('REWARD')
             eng.sync()
             out['config']['host_boundary_env_steps_per_s'] = B * n_host / (time.perf_counter() - t_h)
+        if world == 1 and not SPLIT and exchange is None and not args.headline_only:
+            # The same closed loops with the RESTART MEMO on (ppn_restart_memo, round 6; opt-in, never the headline): the fused restart of
+            # an episode that ends sits behind the longest chain of a launch -- served from a snapshot it is a copy.  48 warm-up steps
+            # (the engine's learning steps); every 16th step after that is a learning step as well and is inside the timed loop.
+            try:
+                eng.restart_memo(True)
+                n_obs = eng.observation_length('full')
+                obs_t = torch.empty((B, n_obs), dtype=torch.float64, device='cuda:%d' % local_rank)
+                nb = obs_t.numel() * obs_t.element_size()
+                for _ in range(48):
+                    eng.step_observe_device(aptr, obs_t.data_ptr(), nb, auto_reset=True, layout='full', dtype=np.float64)
+                eng.sync()
+                c0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+                t_o = time.perf_counter()
+                for _ in range(args.steps):
+                    eng.step_observe_device(aptr, obs_t.data_ptr(), nb, auto_reset=True, layout='full', dtype=np.float64)
+                eng.sync()
+                out['config']['closed_loop_with_observation_restart_memo_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - c0) / (time.perf_counter() - t_o)
+                del obs_t
+                if not args.no_rollout:
+                    eng.rollout_policy('line_relief', [1.0], 3)
+                    eng.sync()
+                    p0 = int(eng.read('N_STEPS').astype(np.int64).sum())
+                    t_p = time.perf_counter()
+                    eng.rollout_policy('line_relief', [1.0], args.steps)
+                    eng.sync()
+                    out['config']['closed_loop_device_policy_rollout_restart_memo_env_steps_per_s'] = (int(eng.read('N_STEPS').astype(np.int64).sum()) - p0) / (time.perf_counter() - t_p)
+                out['config']['restart_memo_served'] = eng.restart_memo_stats()['served']
+            except Exception as ex:
+                out['config']['restart_memo_error'] = str(ex)[:120]
+            finally:
+                eng.restart_memo(False)
         if world == 1 and not SPLIT and not args.no_other_configs and B == BATCH_PER_GPU and exchange is None:
             eng.close()
             long_form = other_configs(local_rank, AUTO_RESET, max(12, min(40, args.steps)))

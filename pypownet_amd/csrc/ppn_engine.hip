@@ -242,7 +242,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     for (unsigned k : order) {
       const int e_ = (int)(unsigned)(a.q_items[k & a.q_mask] & 0xFFFFFFFFull);
       memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));
-      body_step<W, NT>(a.d, a.st, S, a.actions, 0, 1, a.restart_prio, e_, 0);
+      body_step<W, NT, true>(a.d, a.st, S, a.actions, 0, 1, a.restart_prio, e_, 0, -1, a.memo);
       if (a.obs) { if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, e_, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, e_, 0); }
       if (a.report_out) for (int j = 0; j < 3; ++j) a.report_out[3 * (size_t)e_ + j] = a.st.report[3 * (size_t)e_ + j];
       const unsigned c = a.q_ctl[3]++;
@@ -257,7 +257,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
       const int e_ = a.perm ? a.perm[k_] : k_;
       memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));
       policy_action<W>(a.d, a.st, a.policy, e_, a.policy_out + (size_t)e_ * a.d.alen, 0);
-      body_step<W, NT>(a.d, a.st, S, a.policy_out, 0, 1, a.restart_prio, e_, 0);
+      body_step<W, NT, true>(a.d, a.st, S, a.policy_out, 0, 1, a.restart_prio, e_, 0, -1, a.memo);
     }
     return 0;
   }
@@ -266,7 +266,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
     if (KIND == K_STEP || KIND == K_ROLLOUT || KIND == K_STEP_PERSIST) { for (int s_ = 0; s_ < a.n_steps; ++s_) body_step<W, NT>(a.d, a.st, S, a.actions + (size_t)s_ * a.action_step_stride, a.sim, a.auto_reset, a.restart_prio, env, 0, a.cap_class); }
     else if (KIND == K_STEP_OBS) {
       if (a.cap_class >= 0 && (int)a.st.big[env] != a.cap_class) continue;
-      body_step<W, NT>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, a.restart_prio, env, 0, a.cap_class);
+      body_step<W, NT, true, true>(a.d, a.st, S, a.actions, a.sim, a.auto_reset, a.restart_prio, env, 0, a.cap_class, a.memo);
       if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, env, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, env, 0);
     }
     else if (KIND == K_GAMEOVER) body_game_over<W, NT>(a.d, a.st, S, a.valid, a.sim, env, 0, a.memo);
@@ -1511,9 +1511,13 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
       dact = e->d_actions;
     }
   }
-  const int mode = simulate ? 0 : (auto_reset == 2 ? 2 : (auto_reset ? 1 : 0));
-  if (mode != 2) { int rcs = settle_restarts(e); if (rcs) return rcs; }
-  else if (e->d_memo && e->pending_restart) {
+  const int mode_asked = simulate ? 0 : (auto_reset == 2 ? 2 : (auto_reset ? 1 : 0));
+  if (mode_asked != 2) { int rcs = settle_restarts(e); if (rcs) return rcs; }
+  // (Restart memo under the FUSED restart -- ppn_step_observe, the rollouts, the step server: those kernels serve a restart from its
+  //  snapshot when there is one and save the ones they had to compute themselves, body_episode<MEMO, APPLY>; nothing to do here.  The
+  //  plain step kernel is compiled without either: ppn_step(auto_reset = 1) computes every restart.)
+  const int mode = mode_asked;
+  if (mode_asked == 2 && e->d_memo && e->pending_restart) {
     // restart memo, in front of the step kernel: (1) the owed restarts that have a snapshot are served by a light kernel; (2) a
     // LEARNING pass of the game-over kernel computes and saves the eligible ones that have none yet (body_game_over, only_owed = 2) --
     // run in the first steps after the memo was set up and every n-th step afterwards (positions that come up rarely): it is carved

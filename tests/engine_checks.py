@@ -1020,6 +1020,73 @@ def check_restart_memo(lib_path, envname='default118', steps=40, batch=64, limit
     return st
 
 
+def check_restart_memo_fused(lib_path, envname='default118', steps=40, batch=64, limits_file='bench_limits.json', max_active_buses=118, seed=13,
+                             random_acts=False, solver='newton', layout='full', dtype=np.float64, rollout_steps=6, start_spread=1):
+    """The restart memo under the FUSED restart: ppn_step_observe(auto_reset = 1) -- the step, the restart of an episode that ended and
+    the observation rows in one call -- and the closed-loop rollout kernel, on an engine with the memo against one without: the rows
+    every call returns, every state field after every call (N_SOLVES / N_ITERS / EPOCH included), the trajectories of a
+    ppn_rollout_policy launch at the end.  Learning steps (deferred step + game-over pass + gather) and served restarts (the snapshot
+    copied inside the step kernel) must both be indistinguishable from the plain fused launch."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env(envname, conf={'solver': solver})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    kw = {}
+    if limits_file:
+        with open(os.path.join(ENVS, envname, limits_file)) as f:
+            kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
+    if max_active_buses:
+        kw['max_active_buses'] = max_active_buses
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)
+    b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)
+    b.restart_memo(True)
+    slots, t0 = default_assignment(np.arange(batch) * start_spread, chronics)
+    for e in (a, b):
+        e.reset(chronic_slot=slots, t0=t0)
+    n = a.observation_length(layout)
+    item = np.dtype(dtype).itemsize
+    rng = np.random.default_rng(seed)
+    gpu = lib_path is None
+    if gpu:
+        import torch
+        tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        act_d = torch.zeros((batch, case.action_length), dtype=torch.uint8, device='cuda')
+        oa, ob = (torch.full((batch, n), -7.0, dtype=tdt, device='cuda') for _ in range(2))
+        torch.cuda.synchronize()
+    else:
+        act_h = np.zeros((batch, case.action_length), dtype=np.uint8)
+        oa, ob = (np.full((batch, n), -7.0, dtype=dtype) for _ in range(2))
+    n_done = 0
+    for t in range(steps):
+        acts = random_actions(case, rng, batch) if random_acts else np.zeros((batch, case.action_length), dtype=np.uint8)
+        if gpu:
+            act_d.copy_(torch.from_numpy(acts)); torch.cuda.synchronize()
+            ap, pa, pb = act_d.data_ptr(), oa.data_ptr(), ob.data_ptr()
+        else:
+            act_h[:] = acts
+            ap, pa, pb = act_h.ctypes.data, oa.ctypes.data, ob.ctypes.data
+        a.step_observe_device(ap, pa, batch * n * item, auto_reset=True, layout=layout, dtype=dtype)
+        b.step_observe_device(ap, pb, batch * n * item, auto_reset=True, layout=layout, dtype=dtype)
+        a.sync(); b.sync()
+        ha, hb = (oa.cpu().numpy(), ob.cpu().numpy()) if gpu else (oa, ob)
+        assert np.array_equal(ha, hb, equal_nan=True), (t, np.argwhere(ha != hb)[:5])
+        for f in STATE_FIELDS + ('EPOCH', 'RETURN', 'BUS_TYPE', 'STEP_REPORT'):
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (t, f)
+        n_done += int(a.read('DONE').sum())
+    st = b.restart_memo_stats()
+    if rollout_steps:      # the closed-loop rollout kernel serves from the same snapshots (it never saves)
+        for e in (a, b):
+            e.rollout_policy('do_nothing', [], rollout_steps)
+        for f in STATE_FIELDS + ('EPOCH', 'RETURN', 'BUS_TYPE'):
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), ('rollout', f)
+        st['served_with_rollout'] = b.restart_memo_stats()['served']
+    a.close(); b.close()
+    st['episodes_ended'] = n_done
+    return st
+
+
 def check_rollout_equals_steps(lib_path, envname='default118', batch=24, n_steps=9, bench_limits=True, random_acts=False, seed=5,
                                modes=(1, 2, 0)):
     """ppn_rollout (n_steps Game.step calls per environment in one launch, every environment running ahead on its own) leaves

@@ -154,6 +154,19 @@ def test_emu_restart_memo(emu_lib, kw):
     print(kw, st)
 
 
+@pytest.mark.parametrize('kw', [
+    dict(steps=44, batch=10, limits_file='bench_limits_110.json'),
+    dict(steps=44, batch=8),
+    dict(steps=40, batch=6, random_acts=True, max_active_buses=0, layout='minimalist', dtype=np.float32),
+])
+def test_emu_restart_memo_under_the_fused_restart(emu_lib, kw):
+    """The memo where the restart happens in the launch that ended the episode (ppn_step_observe, ppn_rollout_policy): learning steps
+    and served restarts against the plain fused launches."""
+    st = ec.check_restart_memo_fused(emu_lib, **kw)
+    assert st['episodes_ended'] > 0 and st['snapshots'] > 0, st
+    print(kw, st)
+
+
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_emu_repacked_schedule(emu_lib, solver):
     """Pivots and Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle."""

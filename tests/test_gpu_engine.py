@@ -101,6 +101,19 @@ def test_gpu_restart_memo(kw):
     assert st['episodes_ended'] > 0 and st['snapshots'] > 0 and st['served'] > 0, st
 
 
+@pytest.mark.parametrize('kw', [
+    dict(steps=48, batch=2048),                                                                       # the bench workload: learning steps, then restarts served inside K_STEP_OBS
+    dict(steps=40, batch=512, limits_file='bench_limits_110.json'),
+    dict(steps=40, batch=512, random_acts=True, max_active_buses=0, layout='minimalist', dtype=np.float32),      # four-word kernels, two-capacity stepping
+])
+def test_gpu_restart_memo_under_the_fused_restart(kw):
+    """The memo where the restart happens in the launch that ended the episode: ppn_step_observe(auto_reset = 1) and the closed-loop
+    rollout kernel serve restarts from snapshots INSIDE the kernel (body_episode<APPLY>), learning steps are played as a deferred
+    step + game-over pass + gather -- rows, every state field and the counters bit for bit those of an engine without the memo."""
+    st = ec.check_restart_memo_fused(HIP, **kw)
+    assert st['episodes_ended'] > 0 and st['snapshots'] > 0 and st['served'] > 0 and st['served_with_rollout'] > st['served'], st
+
+
 def test_gpu_full_size_bench_workload_with_restart_memo():
     """The 4096 x 60 lock-step of the headline workload against the C oracle with the memo on (PPN_RESTART_MEMO=1): flags, line
     status, counters, chronic positions, cumulative solves and Newton iterations bit-exact, voltages <= 1e-8 -- served restarts

@@ -37,6 +37,15 @@ def run(variant, B, K):
         zero = np.zeros((B, 32), dtype=np.int64)
         eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
         anat0 = (eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum())
+    if 'memo' in variant:      # restart memo on, warmed by 40 fused steps (the engine's learning steps)
+        eng.restart_memo(True)
+        for _ in range(40):
+            eng.step(acts_h, auto_reset=True)
+        eng.sync()
+        if os.environ.get('PPN_ASYNC_ANATOMY'):
+            zero = np.zeros((B, 32), dtype=np.int64)
+            eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
+            anat0 = (eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum())
     if 'rollout' in variant:      # reference point: the device-policy rollout kernel (no host in the loop, no observation)
         eng.rollout_policy('do_nothing', [], 3); eng.sync()
         t_ = time.perf_counter(); eng.rollout_policy('do_nothing', [], K); eng.sync()
@@ -56,6 +65,8 @@ def run(variant, B, K):
                 unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
                 print('      %-44s %8.0f cyc per %s' % (name, tot[k] / {'iteration': nit, 'env-step': n, 'solve': nsolve}[unit], unit))
             print('      %-44s %8.0f cyc and %.1f us per env-step' % ('step body', tot[14] / n, tot[15] / n * 1e-2))
+            if 'memo' in variant:
+                print('      restart memo:', eng.restart_memo_stats())
         eng.close()
         return
     wg = [int(v[2:]) for v in variant.split('+') if v.startswith('wg')]
