@@ -1710,26 +1710,32 @@ extern "C" int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* p
 }
 
 // ---- topology-action search: K candidate actions evaluated from the current state of chosen environments --------------
+// The fork of ppn_simulate_candidates copies ~40 per-environment rows per candidate: ONE launch over a table of (destination, source,
+// bytes) instead of one launch per field (round 6: 42 launches of a few microseconds each were 8 % of a search round).
+#define PPN_FORK_MAX_FIELDS 48
+struct ForkTable { unsigned char* dst[PPN_FORK_MAX_FIELDS]; const unsigned char* src[PPN_FORK_MAX_FIELDS]; unsigned bytes[PPN_FORK_MAX_FIELDS]; int n_fields; };
 #ifndef PPN_EMU
-__global__ void __launch_bounds__(256) ppn_gather_rows(unsigned char* dst, const unsigned char* src, const int* idx,
-                                                       size_t row_bytes) {
-  const unsigned char* s = src + (size_t)idx[blockIdx.x] * row_bytes;
-  unsigned char* d = dst + (size_t)blockIdx.x * row_bytes;
-  if (((row_bytes | (size_t)s | (size_t)d) & 15) == 0) {
-    for (size_t k = threadIdx.x; k < row_bytes / 16; k += 256) ((uint4*)d)[k] = ((const uint4*)s)[k];
-  } else {
-    for (size_t k = threadIdx.x; k < row_bytes; k += 256) d[k] = s[k];
+__global__ void __launch_bounds__(256) ppn_fork_rows(const ForkTable t, const int* idx) {
+  const size_t c = blockIdx.x, e_ = (size_t)idx[blockIdx.x];
+  for (int f = 0; f < t.n_fields; ++f) {
+    const size_t rb = t.bytes[f];
+    const unsigned char* s = t.src[f] + e_ * rb;
+    unsigned char* d = t.dst[f] + c * rb;
+    if (((rb | (size_t)s | (size_t)d) & 15) == 0) { for (size_t k = threadIdx.x; k < rb / 16; k += 256) ((uint4*)d)[k] = ((const uint4*)s)[k]; }
+    else if (((rb | (size_t)s | (size_t)d) & 3) == 0) { for (size_t k = threadIdx.x; k < rb / 4; k += 256) ((unsigned*)d)[k] = ((const unsigned*)s)[k]; }
+    else { for (size_t k = threadIdx.x; k < rb; k += 256) d[k] = s[k]; }
   }
 }
 #endif
-static int gather_rows(ppn_engine* e, void* dst, const void* src, const int* d_idx, const int* h_idx, size_t row_bytes, int n) {
+static int fork_rows(ppn_engine* e, const ForkTable& t, const int* d_idx, const int* h_idx, int n) {
 #ifdef PPN_EMU
   (void)e; (void)d_idx;
-  for (int c = 0; c < n; ++c) memcpy((char*)dst + (size_t)c * row_bytes, (const char*)src + (size_t)h_idx[c] * row_bytes, row_bytes);
+  for (int f = 0; f < t.n_fields; ++f)
+    for (int c = 0; c < n; ++c) memcpy(t.dst[f] + (size_t)c * t.bytes[f], t.src[f] + (size_t)h_idx[c] * t.bytes[f], t.bytes[f]);
   return 0;
 #else
   (void)h_idx;
-  hipLaunchKernelGGL(ppn_gather_rows, dim3(n), dim3(256), 0, e->stream, (unsigned char*)dst, (const unsigned char*)src, d_idx, row_bytes);
+  hipLaunchKernelGGL(ppn_fork_rows, dim3(n), dim3(256), 0, e->stream, t, d_idx);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 #endif
 }
@@ -1780,7 +1786,8 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
   const bool cand_prepass = e->sched_prepass && e->W == 4 && e->dc.NB > e->dc.nS && e->lds_sched <= 64 * 1024 && e->cand_cache;
   int rc = 0;
   DevState* dst = &e->cand; const DevState* src = &e->st;
-#define GR(m, type, cnt) rc |= gather_rows(e, dst->m, src->m, e->d_cand_ids, env_ids, sizeof(type) * (size_t)(cnt), n);
+  ForkTable ft; ft.n_fields = 0;
+#define GR(m, type, cnt) { const int f_ = ft.n_fields++; ft.dst[f_] = (unsigned char*)dst->m; ft.src[f_] = (const unsigned char*)src->m; ft.bytes[f_] = (unsigned)(sizeof(type) * (size_t)(cnt)); }
   GR(vm, double, d.nrows) GR(va, double, d.nrows) GR(pg, double, d.nP) GR(qg, double, d.nP) GR(vg, double, d.nP)
   GR(pd, double, d.nL) GR(qd, double, d.nL) GR(pf, double, d.nl) GR(qf, double, d.nl) GR(pt, double, d.nl)
   GR(qt, double, d.nl) GR(amps, double, d.nl) GR(pn, u8, d.nP) GR(ln, u8, d.nL) GR(on, u8, d.nl) GR(en, u8, d.nl)
@@ -1790,6 +1797,8 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
   GR(npc, int, 1) GR(epoch, int, 1) GR(prow, int, 1) GR(lev, u8, d.nl) GR(src, int, 1) GR(draws, unsigned, 1)
   if (!cand_prepass) { GR(ws_tri, u64, d.TCAP) GR(ws_pair, u64, d.MCAP) GR(ws_piv, unsigned, d.NB) GR(ws_cache, u8, d.cache_stride) }
 #undef GR
+  static_assert(PPN_FORK_MAX_FIELDS >= 44, "the fork table holds every row of the fork");
+  rc |= fork_rows(e, ft, e->d_cand_ids, env_ids, n);
   if (rc) return fail(e, PPN_E_HIP, "state fork failed: %s", dev_err());
   KArgs a = make_args(e, false);
   a.st = e->cand;

@@ -1020,6 +1020,41 @@ def check_restart_memo(lib_path, envname='default118', steps=40, batch=64, limit
     return st
 
 
+def check_restart_memo_invalidation(lib_path, batch=12, steps=14):
+    """Snapshots are restarts under ONE set of thermal limits: ppn_set_thermal_limits drops them (a restart's cascade cuts lines by
+    those limits).  Memo engine against a plain one across a change of limits, every state field."""
+    import json
+    import os
+    from helpers import ENVS
+    from pypownet_amd.batched import default_assignment
+    case, cfg, chronics = load_env('default118', conf={'solver': 'newton'})
+    lim = {}
+    for name in ('bench_limits.json', 'bench_limits_110.json'):
+        with open(os.path.join(ENVS, 'default118', name)) as f:
+            lim[name] = np.asarray(json.load(f)['limits_a'])
+    a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, thermal_limits=lim['bench_limits_110.json'], max_active_buses=118)
+    b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, thermal_limits=lim['bench_limits_110.json'], max_active_buses=118)
+    b.restart_memo(True)
+    slots, t0 = default_assignment(np.arange(batch), chronics)
+    for e in (a, b):
+        e.reset(chronic_slot=slots, t0=t0)
+    acts = np.zeros((batch, case.action_length), dtype=np.uint8)
+    held = []
+    for phase, name in enumerate(('bench_limits_110.json', 'bench_limits.json', 'bench_limits_110.json')):
+        if phase:
+            for e in (a, b):
+                e.set_thermal_limits(lim[name])
+            assert b.restart_memo_stats()['snapshots'] == 0      # dropped with the limits they were computed under
+        for t in range(steps):
+            a.step(acts, auto_reset=2); b.step(acts, auto_reset=2)
+            if t % 4 == 3 or t == steps - 1:
+                for f in STATE_FIELDS + ('EPOCH', 'RETURN'):
+                    assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (phase, t, f)
+        held.append(b.restart_memo_stats()['snapshots'])
+    a.close(); b.close()
+    return held
+
+
 def check_restart_memo_fused(lib_path, envname='default118', steps=40, batch=64, limits_file='bench_limits.json', max_active_buses=118, seed=13,
                              random_acts=False, solver='newton', layout='full', dtype=np.float64, rollout_steps=6, start_spread=1):
     """The restart memo under the FUSED restart: ppn_step_observe(auto_reset = 1) -- the step, the restart of an episode that ended and
@@ -1369,7 +1404,7 @@ def check_step_observe(lib_path, envname='default14', batch=6, n_steps=12, solve
 
 def check_async_equals_stepping(lib_path, envname='default118', batch=8, n_steps=10, solver='newton', bench_limits=True, layout='full',
                                 dtype=np.float64, min_ready=3, seed=5, rows_by_env=False, device_actions=False, settle_at=None,
-                                workgroups=0, idle_timeout_ms=0, pause_s=0.0, **engine_kw):
+                                workgroups=0, idle_timeout_ms=0, pause_s=0.0, memo_warm=0, **engine_kw):
     """ppn_async_start / ppn_send / ppn_recv (an external policy on every environment's own clock) against ppn_step(auto_reset = 1):
     environment e's k-th step gets the same action on both sides (random node-splitting / line-switching rows drawn per (step, env));
     what every ppn_recv hands out -- the environment's observation row and its report row (done, flag, reward sum) -- is compared with
@@ -1392,10 +1427,17 @@ def check_async_equals_stepping(lib_path, envname='default118', batch=8, n_steps
             kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
     a = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)      # stepped
     b = engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw)      # asynchronous session
+    if memo_warm:      # the restart memo under the step server (it serves, never saves): snapshots learned by an engine life before the session
+        b.restart_memo(True)
     slots, t0 = default_assignment(np.arange(batch) * 7, chronics)
     for e in (a, b):
         e.reset(chronic_slot=slots, t0=t0)
         e.process_game_over()      # (environments that are over right after the reset: restarted before the first step on both sides)
+    for _ in range(memo_warm):       # do-nothing steps with the deferred restart on BOTH engines: b's learning passes fill its memo
+        for e in (a, b):
+            e.step(np.zeros((batch, case.action_length), dtype=np.uint8), auto_reset=2)
+    for e in (a, b):
+        e.sync()
     rng = np.random.default_rng(seed)
     acts = [random_actions(case, rng, batch, p_node=0.5, p_line=0.3) for _ in range(n_steps)]
     n_obs = a.observation_length(layout)
@@ -1475,9 +1517,10 @@ def check_async_equals_stepping(lib_path, envname='default118', batch=8, n_steps
     for f in STATE_FIELDS + ('EPOCH', 'RETURN', 'STEP_REPORT'):
         assert np.array_equal(a.read(f), b.read(f), equal_nan=True), f
     assert np.array_equal(a.observations(layout=layout, dtype=dtype), b.observations(layout=layout, dtype=dtype), equal_nan=True)
-    assert int(b.read('N_STEPS').sum()) <= batch * n_steps
+    assert int(b.read('N_STEPS').sum()) <= batch * (n_steps + memo_warm)
+    memo_served = b.restart_memo_stats()['served'] if memo_warm else 0
     a.close(); b.close()
-    return dict(steps=total, receives=n_recv, settled=n_settled, done=int(sum(int(r[:, 0].sum()) for r in want_rep)),
+    return dict(steps=total, receives=n_recv, settled=n_settled, done=int(sum(int(r[:, 0].sum()) for r in want_rep)), memo_served=memo_served,
                 apart=int(step_of.max() - step_of.min()), restarts=st['server_restarts'], republished=st['republished'],
                 workgroups=st['workgroups'], out_of_order=int(order_seen[:batch] != sorted(order_seen[:batch])))
 

@@ -167,6 +167,18 @@ def test_emu_restart_memo_under_the_fused_restart(emu_lib, kw):
     print(kw, st)
 
 
+def test_emu_restart_memo_is_dropped_with_the_thermal_limits(emu_lib):
+    held = ec.check_restart_memo_invalidation(emu_lib)
+    assert all(h > 0 for h in held), held
+
+
+def test_emu_async_session_with_restart_memo(emu_lib):
+    """The step server serves restarts from snapshots an earlier life of the engine learned (deferred steps with learning passes)."""
+    st = ec.check_async_equals_stepping(emu_lib, 'default118', batch=12, n_steps=10, solver='newton', min_ready=3, max_active_buses=118,
+                                        memo_warm=12)
+    assert st['steps'] == 120 and st['done'] > 0, st
+
+
 @pytest.mark.parametrize('solver', ['newton', 'fdxb'])
 def test_emu_repacked_schedule(emu_lib, solver):
     """Pivots and Schur rounds of the shared schedule re-packed on the host vs the schedule as built, and the oracle."""

@@ -114,6 +114,19 @@ def test_gpu_restart_memo_under_the_fused_restart(kw):
     assert st['episodes_ended'] > 0 and st['snapshots'] > 0 and st['served'] > 0 and st['served_with_rollout'] > st['served'], st
 
 
+def test_gpu_restart_memo_is_dropped_with_the_thermal_limits():
+    held = ec.check_restart_memo_invalidation(HIP, batch=256, steps=16)
+    assert all(h > 0 for h in held), held
+
+
+def test_gpu_async_session_with_restart_memo():
+    """K_SERVE with the memo: restarts of episodes that end inside the step server are served from snapshots learned before the
+    session; rows, reports and final state bit for bit those of the stepped engine (which computes every restart)."""
+    st = ec.check_async_equals_stepping(None, 'default118', batch=1024, n_steps=10, solver='newton', min_ready=256, max_active_buses=118,
+                                        memo_warm=36)
+    assert st['steps'] == 10240 and st['done'] > 0 and st['memo_served'] > 0, st
+
+
 def test_gpu_full_size_bench_workload_with_restart_memo():
     """The 4096 x 60 lock-step of the headline workload against the C oracle with the memo on (PPN_RESTART_MEMO=1): flags, line
     status, counters, chronic positions, cumulative solves and Newton iterations bit-exact, voltages <= 1e-8 -- served restarts
