@@ -231,8 +231,9 @@ int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c);
  * environment whose counters are all below n_timesteps_consecutive_soft_overflow_breaks copies it; the cumulative solve / iteration
  * counters (PPN_F_N_SOLVES, PPN_F_N_ITERS) and the epoch move by what the computed restart added, so every field reads as if the
  * restart had been computed (tests: check_restart_memo, bit for bit against an engine without it, and the oracle lock-steps run
- * with PPN_RESTART_MEMO=1).  Served where ppn_step restarts with auto_reset = 2 (the deferred restart); not used with
- * PPN_LOOP_RANDOM.  max_bytes: memory the snapshots may take (<= 0: 1 GiB); snapshots are dropped when chronics or thermal limits
+ * with PPN_RESTART_MEMO=1).  Served where ppn_step restarts with auto_reset = 2 (the deferred restart) and inside ppn_step_observe,
+ * ppn_rollout_policy and the step server of an asynchronous session (ppn_step_observe also saves what it computes; the other two
+ * only serve); ppn_step(auto_reset = 1) and ppn_rollout compute every restart.  Not used with PPN_LOOP_RANDOM.  max_bytes: memory the snapshots may take (<= 0: 1 GiB); snapshots are dropped when chronics or thermal limits
  * change.  bench.py's headline keeps it OFF: every restart of the timed region is a computed one, as the reference's is. */
 int ppn_restart_memo(ppn_engine* e, int32_t enable, int64_t max_bytes);
 /* 0 snapshots held, 1 restarts served from a snapshot, 2 restarts that were not eligible (a soft-overflow counter at its threshold),
