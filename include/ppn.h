@@ -305,6 +305,9 @@ int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device
 #define PPN_POLICY_DO_NOTHING 0
 #define PPN_POLICY_LINE_RELIEF 1
 int ppn_policy_actions(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, uint8_t* actions_out_device);
+/* (ppn_rollout_policy's kernel is the one whose first version faulted on the GPU only -- tools/ubench/README_gpu_only_failures.md: the
+ * cause is a code-generation problem that was pinned, not found.  Its gates: test_gpu_policy_rollout_equals_stepping in the `-m gpu`
+ * suite and tools/ubench/gpu_only_failure_repro.sh; run both after any change of compiler or of the kernels' loop structure.) */
 int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* params, int32_t n_params, int32_t n_steps);
 /* ---- asynchronous stepping for EXTERNAL policies: send / recv (libppn 0.3) ------------------------------------------------------
  * The reference's consumers are agents that LOOK at the observation and then act (pypownet/runner.py:72-103: obs -> agent.act ->
