@@ -29,8 +29,9 @@ def main():
     orc.reset(chronic_slot=slots, t0=t0)
     act = np.zeros((B, case.action_length), dtype=np.uint8)
     worst = 0.0
+    AR = int(os.environ.get('PPN_SOAK_AUTO_RESET', '1'))      # (2 + PPN_RESTART_MEMO=1: the restart memo against the oracle, which knows none)
     for t in range(steps):
-        eng.step(act, auto_reset=True)
+        eng.step(act, auto_reset=AR if AR == 2 else True)
         orc.step(act, auto_reset=True)
         if (t + 1) % every and t + 1 != steps:
             continue
@@ -45,8 +46,9 @@ def main():
         da = np.abs(np.deg2rad(eng.read('VA')[live]) - np.deg2rad(orc.read('VA')[live])).max()
         worst = max(worst, dv, da)
         assert dv <= 1e-8 and da <= 1e-8, (t, dv, da)
-    print('soak ok: %d environments x %d steps, %d solves, max |dV| %.2e'
-          % (B, steps, int(orc.read('N_SOLVES').astype(np.int64).sum()), worst))
+    print('soak ok: %d environments x %d steps, %d solves, max |dV| %.2e%s'
+          % (B, steps, int(orc.read('N_SOLVES').astype(np.int64).sum()), worst,
+             ('; restart memo: %r' % eng.restart_memo_stats()) if os.environ.get('PPN_RESTART_MEMO') else ''))
 
 
 if __name__ == '__main__':
