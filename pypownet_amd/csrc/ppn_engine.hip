@@ -233,7 +233,7 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
   if (KIND == K_SERVE) {
     // the step server of an asynchronous session, emulated: every item published so far is played NOW, in a pseudo-random order (on
     // the GPU they complete in whatever order their cascades end), each followed by its completion record
-    unsigned head = a.q_ctl[0]; const unsigned tail = a.q_ctl[1];
+    unsigned head = a.q_ctl[QC_HEAD]; const unsigned tail = a.q_ctl[QC_TAIL];
     for (unsigned k = head; k != tail; ++k) if ((unsigned)(a.q_items[k & a.q_mask] >> 32) != k + 1u) return -1;      // (every published slot carries its stamp)
     std::vector<unsigned> order;
     for (unsigned k = head; k != tail; ++k) order.push_back(k);
@@ -245,10 +245,10 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
       body_step<W, NT, true>(a.d, a.st, S, a.actions, 0, 1, a.restart_prio, e_, 0, -1, a.memo);
       if (a.obs) { if (a.obs_f32) body_obs<W, float>(a.d, a.st, S, (float*)a.obs, a.obs_sections, a.obs_stride, e_, 0); else body_obs<W, double>(a.d, a.st, S, (double*)a.obs, a.obs_sections, a.obs_stride, e_, 0); }
       if (a.report_out) for (int j = 0; j < 3; ++j) a.report_out[3 * (size_t)e_ + j] = a.st.report[3 * (size_t)e_ + j];
-      const unsigned c = a.q_ctl[3]++;
+      const unsigned c = a.q_ctl[QC_DONE]++;
       a.q_done[c & a.q_mask] = ((unsigned long long)(c + 1u) << 32) | (unsigned)e_;
     }
-    a.q_ctl[0] = tail;
+    a.q_ctl[QC_HEAD] = tail;
     return 0;
   }
   if (KIND == K_POLICY_ROLLOUT) {      // the items in their hand-out order: (step, environment)
@@ -1703,6 +1703,7 @@ extern "C" int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* p
     }
     const int slots_ = resident_slots_of(e);
     nblocks = std::max(1, std::min(slots_ > 0 ? slots_ : e->batch, e->batch));
+    { const char* v = getenv("PPN_ROLLOUT_WORKGROUPS"); if (v && atoi(v) > 0) nblocks = std::min(nblocks, atoi(v)); }      // (experiments: the rollout kernel at the step server's occupancy)
   }
 #endif
   if (launch<K_POLICY_ROLLOUT>(e, a, nblocks, true)) return fail(e, PPN_E_HIP, "policy rollout launch failed: %s", dev_err());

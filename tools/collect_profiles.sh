@@ -19,6 +19,7 @@ if [ -x $ROOT/build/hbm_counter_calib ]; then
   python $ROOT/tools/ubench/hbm_counter_calib.py $OUT/calib_write $OUT/calib_fetch > $OUT/hbm_counter_calib.json 2> $OUT/hbm_counter_calib.err
 fi
 cd $ROOT
+if [ -n "$PPN_COLLECT_PMC_ONLY" ]; then ls $OUT; exit 0; fi      # (a library rebuilt after the long collection: only the passes roofline.traffic is read from)
 # every kernel of the default bench run (headline + the other configurations: W = 1 and W = 4 step kernels too)
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats_all -o bench_all --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-rollout > $OUT/bench_all_under_rocprof.log 2>&1

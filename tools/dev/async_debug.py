@@ -72,6 +72,10 @@ def run(variant, B, K):
     wg = [int(v[2:]) for v in variant.split('+') if v.startswith('wg')]
     mr = [int(v[2:]) for v in variant.split('+') if v.startswith('mr')]
     mr = mr[0] if mr else 256
+    noise = [int(v[5:]) for v in variant.split('+') if v.startswith('noise')]
+    noise = noise[0] if noise else 0
+    dummy = torch.zeros((1,), dtype=torch.float32, device='cuda')
+    dummy.add_(1); torch.cuda.synchronize()
     if 'noobs' in variant:
         eng.async_start(0, 0, rep_t.data_ptr(), workgroups=wg[0] if wg else 0)
     else:
@@ -90,6 +94,8 @@ def run(variant, B, K):
             ids = eng.recv(min_ready=mr, ids_device_ptr=ids_d.data_ptr() if 'idsdev' in variant else 0)
             tb = time.perf_counter()
             n = len(ids)
+            for _ in range(noise):      # `noiseN`: N kernels that move nothing, on the session's stream -- what do kernel BOUNDARIES cost the resident server?
+                dummy.add_(1)
             if 'hostact' in variant:
                 eng.send(ids, acts_h, rows_by_env=True)
             else:
