@@ -48,8 +48,35 @@ def run(variant, B, K):
             anat0 = (eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum())
     if 'rollout' in variant:      # reference point: the device-policy rollout kernel (no host in the loop, no observation)
         eng.rollout_policy('do_nothing', [], 3); eng.sync()
-        t_ = time.perf_counter(); eng.rollout_policy('do_nothing', [], K); eng.sync()
-        print('%-16s B=%d K=%d: %.3f M env-steps/s (ppn_rollout_policy, do-nothing)' % (variant, B, K, B * K / (time.perf_counter() - t_) / 1e6), flush=True)
+        load = None
+        if 'load' in variant:      # `rollout+load`: while the rollout kernel runs, a second engine launches what a session launches per receive
+            load = Engine(case, conf, 1024, device=0, chronics=chronics, thermal_limits=bench.bench_limits(case), max_active_buses=case.nS)
+            load.reset()
+            lobs = torch.zeros((1024, n_obs), dtype=torch.float64, device='cuda')
+            lsrc = torch.zeros((1024, case.action_length), dtype=torch.uint8, device='cuda'); ldst = torch.zeros_like(lsrc)
+            side = torch.cuda.Stream()
+            load.observations_into_device(lobs.data_ptr(), lobs.numel() * 8); load.wait() if hasattr(load, 'wait') else load.sync()
+            torch.cuda.synchronize()
+        if 'single' in variant:      # `rollout+single`: K launches of ONE step each, waited for one by one (against the server with min_ready = batch)
+            t_ = time.perf_counter()
+            for _ in range(K):
+                eng.rollout_policy('do_nothing', [], 1); eng.sync()
+            print('%-16s B=%d K=%d: %.3f M env-steps/s (K launches of ppn_rollout_policy(1 step), each waited for)' % (variant, B, K, B * K / (time.perf_counter() - t_) / 1e6), flush=True)
+            eng.close()
+            return
+        t_ = time.perf_counter(); eng.rollout_policy('do_nothing', [], K)
+        n_load = 0
+        if load is not None:
+            t_end = time.perf_counter() + B * K / 16e6      # (about as long as the rollout lasts)
+            while time.perf_counter() < t_end:
+                load.observations_into_device(lobs.data_ptr(), lobs.numel() * 8)      # K_OBS over 1024 environments on the other engine's stream
+                with torch.cuda.stream(side):
+                    ldst.copy_(lsrc)                                                   # an enqueue-sized copy
+                n_load += 1
+                time.sleep(100e-6)
+        eng.sync()
+        print('%-16s B=%d K=%d: %.3f M env-steps/s (ppn_rollout_policy, do-nothing)%s' % (variant, B, K, B * K / (time.perf_counter() - t_) / 1e6,
+              (' with %d gather + copy launches beside it' % n_load) if load is not None else ''), flush=True)
         if os.environ.get('PPN_ASYNC_ANATOMY'):
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             from profile_phases import NAMES
