@@ -13,6 +13,21 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import bench  # noqa: E402
 
 
+def hwid_report(out, n_wg):
+    """-DPPN_PROF_HWID builds: slot 31 of profile row w = HW_ID | XCC_ID << 32 of workgroup w -- how many workgroups per CU / per SIMD?"""
+    import collections
+    v = out[:n_wg, 31]
+    if not v.any():
+        return
+    hw = v & 0xFFFFFFFF
+    xcc = (v >> 32) & 0xF
+    simd = (hw >> 4) & 0x3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7
+    per_cu = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+    per_simd = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist(), simd.tolist()))
+    print('      placement of %d workgroups: %d CUs in use, workgroups per CU %s; per SIMD %s' % (
+        n_wg, len(per_cu), dict(sorted(collections.Counter(per_cu.values()).items())), dict(sorted(collections.Counter(per_simd.values()).items()))), flush=True)
+
+
 def run(variant, B, K):
     import torch
     from pypownet_amd.engine import Engine
@@ -91,7 +106,12 @@ def run(variant, B, K):
                     continue
                 unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
                 print('      %-44s %8.0f cyc per %s' % (name, tot[k] / {'iteration': nit, 'env-step': n, 'solve': nsolve}[unit], unit))
+            for k_, name_ in ((16, 'LU level bounds + record prefetch'), (18, "LU phase 1 (U', forward)"), (19, 'LU phase 2 (Schur)'), (30, 'dense tail (inside LU factor)')):
+                print('      %-44s %8.0f cyc per iteration' % (name_, tot[k_] / nit))
+            for k_, name_ in ((20, 'evaluation pass 0 (V, clears)'), (21, 'evaluation pass 1 (Ybus entries)'), (22, 'evaluation pass 2 (buses, norm)')):
+                print('      %-44s %8.0f cyc per evaluation' % (name_, tot[k_] / (nit + nsolve)))
             print('      %-44s %8.0f cyc and %.1f us per env-step' % ('step body', tot[14] / n, tot[15] / n * 1e-2))
+            hwid_report(out, int(os.environ.get('PPN_ROLLOUT_WORKGROUPS', '1792')))
             if 'memo' in variant:
                 print('      restart memo:', eng.restart_memo_stats())
         eng.close()
@@ -154,7 +174,12 @@ def run(variant, B, K):
                 continue
             unit = 'iteration' if k in (4, 5, 6) else ('env-step' if k in (9, 10, 11, 12) else 'solve')
             print('      %-44s %8.0f cyc per %s' % (name, tot[k] / {'iteration': nit, 'env-step': n, 'solve': nsolve}[unit], unit))
+        for k_, name_ in ((16, 'LU level bounds + record prefetch'), (18, "LU phase 1 (U', forward)"), (19, 'LU phase 2 (Schur)'), (30, 'dense tail (inside LU factor)')):
+            print('      %-44s %8.0f cyc per iteration' % (name_, tot[k_] / nit))
+        for k_, name_ in ((20, 'evaluation pass 0 (V, clears)'), (21, 'evaluation pass 1 (Ybus entries)'), (22, 'evaluation pass 2 (buses, norm)')):
+            print('      %-44s %8.0f cyc per evaluation' % (name_, tot[k_] / (nit + nsolve)))
         print('      %-44s %8.0f cyc and %.1f us per env-step' % ('step body', tot[14] / n, tot[15] / n * 1e-2))
+        hwid_report(out, s['workgroups'])
         busy = (out[:, 24].sum() + out[:, 25].sum() + out[:, 26].sum()) * 1e-8
         print('    workgroup-seconds busy %.4f over %.4f s of session -> %.0f workgroups busy on average' % (busy, el, busy / el), flush=True)
     tf = time.perf_counter()
