@@ -62,6 +62,8 @@ def run(variant, B, K):
             eng._check(eng._lib.ppn_write(eng._h, 100, zero.ctypes.data, zero.nbytes), 'write prof')
             anat0 = (eng.read('N_SOLVES').sum(), eng.read('N_ITERS').sum())
     if 'rollout' in variant:      # reference point: the device-policy rollout kernel (no host in the loop, no observation)
+        if 'hoststore' in variant:      # (-DPPN_ROLLOUT_HOST_STORE builds: a session started and stopped leaves its pinned rings to the rollout kernel)
+            eng.async_start(0, 0, rep_t.data_ptr()); eng.async_stop()
         eng.rollout_policy('do_nothing', [], 3); eng.sync()
         load = None
         if 'load' in variant:      # `rollout+load`: while the rollout kernel runs, a second engine launches what a session launches per receive
