@@ -139,6 +139,8 @@ def run(variant, B, K):
             eng.send_device(np.arange(B, dtype=np.int32), acts.data_ptr(), rows_by_env=True)
         total = 0
         while total < B * K:
+            if 'hostsleep' in variant:      # (the host does NOT poll while the server works: is it the polling?)
+                time.sleep(0.03)
             ta = time.perf_counter()
             ids = eng.recv(min_ready=mr, ids_device_ptr=ids_d.data_ptr() if 'idsdev' in variant else 0)
             tb = time.perf_counter()
