@@ -120,6 +120,7 @@ struct ppn_engine {
   u8* d_valid = nullptr;
   int* d_perm = nullptr;            // launch order of the step kernel
   int* d_work = nullptr;            // position counter of the persistent step kernel (ppn_kernels.inc)
+  int* d_xwork = nullptr; int n_xcd = 0;      // per-XCD work counters of the closed-loop rollout kernel (32 ints apart); XCDs of this GPU (0: not probed yet)
   int* d_progress = nullptr;        // ppn_rollout_policy: steps of the launch every environment has completed
   int resident_slots = 0;           // workgroups of the step kernel the GPU holds at once (CUs x environments per CU)
   size_t resident_for = 0;          // ... computed for this LDS size
@@ -943,6 +944,7 @@ extern "C" int ppn_create(const ppn_case* c, const ppn_rules* r, int32_t batch, 
   e->d_valid = dalloc<u8>(e, batch);
   e->d_perm = dalloc<int>(e, batch);
   e->d_work = dalloc<int>(e, 16);
+  e->d_xwork = dalloc<int>(e, 16 * 32);
   e->d_progress = dalloc<int>(e, batch);
   { const char* v = getenv("PPN_PERSISTENT"); if (v && v[0] == '0') e->persistent = false; }
   { const char* v = getenv("PPN_PERSISTENT_ROUNDS"); if (v && atoi(v) > 0) e->persistent_rounds = atoi(v); }
@@ -1690,6 +1692,23 @@ extern "C" int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* p
   a.restart_prio = e->restart_prio;
   a.n_envs = e->batch; a.n_work = e->batch * n_steps;
   a.work_counter = e->d_work; a.progress = e->d_progress;
+#ifndef PPN_EMU
+  if (e->n_xcd == 0) {      // once per engine: how many L2s do workgroups land on?  (PPN_XCD_AFFINE=0: the agent-scope hand-over everywhere)
+    e->n_xcd = 1;
+    const char* v = getenv("PPN_XCD_AFFINE");
+    if (!(v && v[0] == '0')) {
+      int h = 0;
+      if (dev_zero(e->d_xwork, sizeof(int), e->stream)) return fail(e, PPN_E_HIP, "XCD probe failed: %s", dev_err());
+      hipLaunchKernelGGL(ppn_xcc_probe_kernel, dim3(4096), dim3(64), 0, e->stream, e->d_xwork);
+      if (hipStreamSynchronize(e->stream) != hipSuccess || dev_d2h(&h, e->d_xwork, sizeof(int), e->stream)) return fail(e, PPN_E_HIP, "XCD probe failed: %s", dev_err());
+      e->n_xcd = (h >= 0 && h < 16) ? h + 1 : 1;
+    }
+  }
+  if (e->n_xcd > 1 && e->batch >= 2 * e->n_xcd) {      // XCD-affine hand-out: see K_POLICY_ROLLOUT
+    a.n_xcd = e->n_xcd; a.work_counter = e->d_xwork;
+    if (dev_zero(e->d_xwork, sizeof(int) * 16 * 32, e->stream)) return fail(e, PPN_E_HIP, "ppn_rollout_policy: clearing the work counters failed: %s", dev_err());
+  }
+#endif
   int nblocks = e->batch;
   if (dev_zero(e->d_progress, sizeof(int) * (size_t)e->batch, e->stream) || dev_zero(e->d_work, sizeof(int), e->stream))
     return fail(e, PPN_E_HIP, "ppn_rollout_policy: clearing the progress counters failed: %s", dev_err());

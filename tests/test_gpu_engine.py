@@ -612,6 +612,7 @@ def test_gpu_step_report_field_mirrors_done_flag_reward():
 
 
 @pytest.mark.parametrize('env,batch,steps,thr,kw', [('default118', 2048, 12, 0.9, dict(max_active_buses=118)),
+                                                   ('default118', 4096, 24, 0.85, dict(max_active_buses=118)),      # the headline's size: 1 792 workgroups on 8 XCDs hand 4096 environments around (XCD-affine since round 6)
                                                    ('default118', 96, 10, 0.8, dict()),
                                                    ('default14', 512, 30, 0.5, dict())])
 def test_gpu_policy_rollout_equals_stepping(env, batch, steps, thr, kw):
