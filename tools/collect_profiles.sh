@@ -64,3 +64,7 @@ python tools/async_rate.py 4096 60 256,1024,2048 0,1536 2>&1 | grep -v amdgpu.id
 PPN_ASYNC_ANATOMY=1 PPN_DEBUG_LIB=build/libppn_prof.so python tools/dev/async_debug.py 4096 40 devact+idsdev+mr1024 rollout 2>&1 | grep -v amdgpu.ids > $OUT/async_anatomy.txt
 python tools/search_rate.py > $OUT/search_rate.txt 2>&1
 # the 100k-solve random-action soak of the -m gpu suite is the short form of the two soaks above
+# closed-loop rollout kernel (XCD-affine hand-out) against the stepped form at the headline's size, and its rates
+python tests/tools/soak_policy_rollout.py 4096 40 3 2>&1 | grep -v amdgpu.ids | tail -7 > $OUT/soak_policy_rollout.txt
+# the restart memo against the oracle over 300 steps (deferred restart: the memo's apply pass in front of every step)
+PPN_RESTART_MEMO=1 PPN_SOAK_AUTO_RESET=2 python tests/tools/soak_parity.py 4096 300 20 2>&1 | tail -1 > $OUT/soak_parity_restart_memo.txt
