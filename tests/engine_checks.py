@@ -1117,6 +1117,14 @@ def check_restart_memo_fused(lib_path, envname='default118', steps=40, batch=64,
         for f in STATE_FIELDS + ('EPOCH', 'RETURN', 'BUS_TYPE'):
             assert np.array_equal(a.read(f), b.read(f), equal_nan=True), ('rollout', f)
         st['served_with_rollout'] = b.restart_memo_stats()['served']
+        # ... and so does the open-loop rollout with the fused restart (the same kernel, action rows in place of a policy)
+        seq = np.stack([random_actions(case, rng, batch) if random_acts else np.zeros((batch, case.action_length), dtype=np.uint8)
+                        for _ in range(rollout_steps)])
+        for e in (a, b):
+            e.rollout(seq, auto_reset=1)
+        for f in STATE_FIELDS + ('EPOCH', 'RETURN', 'BUS_TYPE'):
+            assert np.array_equal(a.read(f), b.read(f), equal_nan=True), ('open-loop rollout', f)
+        st['served_with_open_loop_rollout'] = b.restart_memo_stats()['served']
     a.close(); b.close()
     st['episodes_ended'] = n_done
     return st
