@@ -96,25 +96,26 @@ __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" :
 #endif
 #define WSYNC_G() __syncthreads()
 #define PPN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)      // the instruction scheduler moves nothing across this point
-// PPN_WAVE_FULL(): a full compiler + EXEC fence at the wave-uniform points of a kernel (round 5).
-// One wavefront plays one environment and every decision between phases is the same in all 64 lanes.  At such a point -- never
-// inside a LANE_LOOP or under a per-lane condition -- the statement (a) sets EXEC to all ones and (b), being an `asm volatile` with a
-// memory clobber, keeps the compiler from moving or merging memory accesses across it.
-// Why it exists: the closed-loop rollout kernel (K_POLICY_ROLLOUT, ppn_kernels.inc) FAULTS on the GPU as first written -- a work
-// loop around policy_action + body_step -- and runs correctly with this statement at the head of the loop (tools/ubench/
-// README_gpu_only_failures.md: reproducer, -DPPN_WAVE_FULL_OFF builds the failing kernel).  What round 5 established about this class
-// of GPU-only failures (also: the round-2 tree with the line-end tables inside the matrix region, rebuilt in variants):
-//   * they do NOT depend on waiting: s_waitcnt lgkmcnt(0), or vmcnt(0) lgkmcnt(0), at every phase boundary changes nothing;
-//   * they DO depend on the optimisation level: the round-2 tree passes at -O1 and -O2 and fails at -O3;
-//   * lanes are NOT found parked: -DPPN_EXEC_CHECK records EXEC != all-ones at these points -- zero events -- and setting EXEC at
-//     the round-2 tree's loop heads does not cure it.  For the rollout kernel ANY volatile statement at the loop head is the cure
-//     (an empty one with a memory clobber, or the EXEC write without the clobber): it pins the loop's shape for the code generator.
-//     Bisecting the LLVM pass pipeline puts the flip at one `simplifycfg` run on the kernel -- a neutral IR clean-up: the faulty
-//     step is downstream (instruction selection / structurisation / allocation of a 29 000-instruction kernel with 500-690 spilled
-//     scalars), not found;
-//   * the lane-serial emulation cannot see them in any lane order (tests/test_emu_lane_order.py): not an ordering assumption of
-//     the kernels' own.
-// It stays at the loop heads as a hardening: one scalar instruction where the phase boundary is a compiler fence anyway.
+// PPN_WAVE_FULL(): a RECONVERGENCE POINT at the head of every wave-uniform loop (round 5; understood in round 6).
+// One wavefront plays one environment and every decision between phases is the same in all 64 lanes.  At the head of such a loop --
+// never inside a LANE_LOOP or under a per-lane condition -- the statement is a side-effecting, convergent instruction that all 64
+// lanes execute together.  What it prevents (tools/ubench/README_gpu_only_failures.md, "Round 6: the root cause of (iii)";
+// tools/ubench/convergent_threading_repro.hip is the same thing in twenty lines):
+//   a work loop that ENDS with `if (lane == 0) publish(...)` and BEGINS with `if (lane == 0) item = atomicAdd(...);
+//   item = readfirstlane(item);` has, per thread, two branches on the same condition in a row across the back edge.  LLVM's SimplifyCFG
+//   threads them: lanes 1..63 jump from the tail straight to the block that holds readfirstlane (their `item` is the constant 0), lane
+//   0 goes round through the atomic.  readfirstlane is a CONVERGENT operation and is now the header of a cycle only lanes 1..63 run:
+//   the structuriser builds two nested loops, lanes 1..63 spin in the inner one with lane 0 masked off, readfirstlane hands them
+//   their own 0, and they replay item 0 for ever with lane 0 missing -- whose stale registers every LANE_READ(x, 0) then takes for
+//   wave-uniform values (the chronic slot and row: the address fault rocgdb caught, EXEC = 0xfffffffffffffffe).
+// With a side-effecting statement in the loop header there is no empty block to thread through, the loop has ONE back edge, and the
+// wave reconverges there by construction.  Any such statement does it (an empty `asm volatile`, `__builtin_amdgcn_wave_barrier()`,
+// this one: all three verified on the engine kernel and on the reproducer); this form also re-arms EXEC and fences memory for the
+// compiler, one scalar instruction where the phase boundary is a compiler fence anyway.
+// Rule for this code base: a loop whose iterations begin or end with lane-0-only code carries PPN_WAVE_FULL at its head (work loops
+// of the persistent / rollout / server kernels, episode loop, cascade loop, around every solve, Newton and fast-decoupled loops).
+// (The two older GPU-only incidents -- round 2: line-end tables inside the matrix region; round 3: B'/B'' assembly -- behaved
+//  differently (no lane missing at the loop heads, -O3 only) and are NOT explained by this; see the README.)
 // -DPPN_EXEC_CHECK additionally records (bit `id` of the environment's prof[31], count in prof[30]) lanes found missing there.
 #if defined(PPN_WAVE_FULL_OFF)      // (the kernels as they were written until round 5: for the reproducer only)
 #define PPN_WAVE_FULL(prof_, id) ((void)0)
@@ -122,6 +123,8 @@ __device__ __forceinline__ int ppn_opaque_uniform(int x) { __asm__ volatile("" :
 #define PPN_WAVE_FULL(prof_, id) __asm__ volatile("" ::: "memory")
 #elif defined(PPN_WAVE_FULL_EXEC_ONLY)         // (reproducer: the EXEC write without the compiler fence)
 #define PPN_WAVE_FULL(prof_, id) __asm__ volatile("s_mov_b64 exec, -1")
+#elif defined(PPN_WAVE_FULL_WAVE_BARRIER)      // (reproducer: the compiler's own convergent no-op)
+#define PPN_WAVE_FULL(prof_, id) __builtin_amdgcn_wave_barrier()
 #elif defined(PPN_EXEC_CHECK)      // (= 2: inside the step body -- ids 4 and up -- lanes found parked are recorded but NOT switched on: where does it start?)
 #define PPN_WAVE_FULL(prof_, id) do { const u64 ex_ = __builtin_amdgcn_read_exec(); \
     if (PPN_EXEC_CHECK != 2 || (id) < 4) __asm__ volatile("s_mov_b64 exec, -1" ::: "memory"); \

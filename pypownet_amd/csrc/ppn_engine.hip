@@ -33,7 +33,16 @@ static int dev_d2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s,
 static int dev_zero(void* d, size_t n, hipStream_t) { memset(d, 0, n); return 0; }
 static const char* dev_err() { return "emulation"; }
 #else
+#ifdef PPN_DEV_MEM_KNOB      // (experiments, DESIGN 12.9: what does the memory type of the state cost / buy?  PPN_DEV_MEM=fine | uncached)
+static int dev_malloc(void** p, size_t n) {
+  const char* v = getenv("PPN_DEV_MEM");
+  if (v && v[0] == 'f') return hipExtMallocWithFlags(p, n ? n : 1, hipDeviceMallocFinegrained) == hipSuccess ? 0 : -1;
+  if (v && v[0] == 'u') return hipExtMallocWithFlags(p, n ? n : 1, hipDeviceMallocUncached) == hipSuccess ? 0 : -1;
+  return hipMalloc(p, n ? n : 1) == hipSuccess ? 0 : -1;
+}
+#else
 static int dev_malloc(void** p, size_t n) { return hipMalloc(p, n ? n : 1) == hipSuccess ? 0 : -1; }
+#endif
 static void dev_free(void* p) { if (p) (void)hipFree(p); }
 static int dev_h2d(void* d, const void* h, size_t n, hipStream_t s) {
   if (hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) != hipSuccess) return -1;

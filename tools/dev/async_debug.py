@@ -91,9 +91,24 @@ def run(variant, B, K):
                     ldst.copy_(lsrc)                                                   # an enqueue-sized copy
                 n_load += 1
                 time.sleep(100e-6)
+        ticks = [int(v[5:]) for v in variant.split('+') if v.startswith('ticks')]
+        n_ticks = 0
+        if ticks:      # `rollout+ticksN`: one kernel that moves nothing every N microseconds on another stream while the rollout kernel runs
+            side = torch.cuda.Stream()
+            tick = torch.zeros((1,), dtype=torch.float32, device='cuda')
+            es = torch.cuda.ExternalStream(eng.stream_ptr(), device='cuda')
+            nxt = time.perf_counter()
+            with torch.cuda.stream(side):
+                while not es.query():
+                    tick.add_(1); n_ticks += 1
+                    nxt += ticks[0] * 1e-6
+                    while time.perf_counter() < nxt:
+                        pass
+        t_launch = time.perf_counter() - t_
         eng.sync()
-        print('%-16s B=%d K=%d: %.3f M env-steps/s (ppn_rollout_policy, do-nothing)%s' % (variant, B, K, B * K / (time.perf_counter() - t_) / 1e6,
-              (' with %d gather + copy launches beside it' % n_load) if load is not None else ''), flush=True)
+        print('%-16s B=%d K=%d: %.3f M env-steps/s (ppn_rollout_policy, do-nothing)%s%s' % (variant, B, K, B * K / (time.perf_counter() - t_) / 1e6,
+              (' with %d gather + copy launches beside it' % n_load) if load is not None else '',
+              (' with %d empty launches beside it (%.0f per ms)' % (n_ticks, n_ticks / t_launch / 1e3)) if ticks else ''), flush=True)
         if os.environ.get('PPN_ASYNC_ANATOMY'):
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             from profile_phases import NAMES
