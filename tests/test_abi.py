@@ -93,3 +93,51 @@ def test_missing_extension_raises(tmp_path, monkeypatch):
     case, cfg, chronics = load_env('default14_for_tests')
     with pytest.raises(ImportError):
         Engine(case, cfg, 1, chronics=chronics)
+
+
+def test_wave_full_statement_keeps_the_work_loop_in_one_piece():
+    """DESIGN 12.9, at compile time (no GPU): the optimised IR of tools/ubench/convergent_threading_repro.hip.  With the statement of
+    PPN_WAVE_FULL at the loop head (FIX=3) the work loop keeps ONE `atomicrmw` for the item counter and one for the work; the
+    miscompiled form (what this compiler makes of FIX=0) carries a third -- the private loop in which lanes 1..63 replay item 0."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'tools', 'ubench', 'convergent_threading_repro.hip')
+
+    def atomics(fix):
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, 'k.ll')
+            subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-DFIX=%d' % fix, '--cuda-device-only', '-emit-llvm', '-S', src, '-o', out],
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            body, on = [], False
+            for line in open(out):
+                if line.startswith('define') and 'work_loop' in line:
+                    on = True
+                if on:
+                    body.append(line)
+                    if line.startswith('}'):
+                        break
+            return sum('atomicrmw' in ln for ln in body), sum('readfirstlane' in ln for ln in body)
+    assert atomics(3) == (2, 1)
+    assert atomics(1) == (2, 1)      # (__builtin_amdgcn_wave_barrier(): the same protection)
+
+
+def test_kernels_ir_has_no_lane_dependent_cycle_around_a_convergent_operation():
+    """tools/dev/ir_lint_convergent.py over the optimised IR of all six kernel translation units (hipcc -emit-llvm, ~30 s in
+    parallel): no cycle that holds a convergent operation (readfirstlane, readlane, barriers, DPP ...) may be left or re-entered on a
+    lane-dependent condition -- the shape simplifycfg gave round 5's rollout kernel.  (The lint reports that kernel in every width
+    and solver when the library is built with -DPPN_WAVE_FULL_OFF: profiles/r06_ir_lint_convergent.txt.)"""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dev', 'ir_lint_convergent.py'), '--build'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(' 0 reported') == 6, r.stdout

@@ -751,3 +751,22 @@ def test_gpu_candidate_slots_keep_their_schedules(solver, batch, k):
     """Round 6: ppn_simulate_candidates' slots keep their schedules across calls -- same outcomes, bit for bit, as
     refilling every slot from its environment at every fork (PPN_CAND_CACHE=0)."""
     assert ec.check_candidate_schedule_cache(None, batch=batch, k=k, rounds=8, solver=solver) > 0
+
+
+@pytest.mark.gpu
+def test_gpu_wave_full_remedy_holds():
+    """the compiler hazard behind round 5's GPU-only failure -- simplifycfg threads a work loop's back edge into the block of
+    a convergent readfirstlane; lanes 1..63 then replay item 0 without lane 0 -- in twenty lines (tools/ubench/
+    convergent_threading_repro.hip, built by __graft_entry__.build_guards).  With the statement the kernels carry at their loop heads
+    (PPN_WAVE_FULL, FIX=3) every (item, lane) cell is played exactly once.  The unprotected form is run too and only reported: with
+    this compiler it is wrong; a compiler that gets it right would not make the remedy wrong."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fixed = os.path.join(root, 'build', 'convergent_threading_repro_fix3')
+    plain = os.path.join(root, 'build', 'convergent_threading_repro_fix0')
+    assert os.path.exists(fixed), 'run python __graft_entry__.py first (build_guards)'
+    r = subprocess.run([fixed], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and '64000 of 64000' in r.stdout and '-> OK' in r.stdout, r.stdout + r.stderr
+    if os.path.exists(plain):
+        r0 = subprocess.run([plain], capture_output=True, text=True, timeout=60)
+        print(r0.stdout.strip())
