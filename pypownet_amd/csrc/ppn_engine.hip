@@ -74,7 +74,7 @@ struct ppn_engine {
   DevState st, sim;
   DevState cand;              // forked states of ppn_simulate_candidates (capacity cand_cap rows)
   int cand_cap = 0, n_cand = 0;
-  u8* d_cand_actions = nullptr; double* d_cand_obs = nullptr; int* d_cand_ids = nullptr;
+  u8* d_cand_actions = nullptr; double* d_cand_obs = nullptr; int* d_cand_ids = nullptr; int* d_cand_perm = nullptr;
   std::vector<void*> allocs;
   std::vector<HostChronic> chronics;
   bool chronics_dirty = true;
@@ -1531,7 +1531,7 @@ static int queue_rollout_launch(ppn_engine* e, KArgs& a, int n_steps) {
     // environments are handed out heaviest first within every step, as the stepped form does (the key of the LAST step before
     // the rollout: it only shapes the start of the launch)
     if (e->order_launches && e->batch > 1024) {
-      hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, (int*)nullptr, 0);
+      hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, (int*)nullptr, 0, (const int*)nullptr);
       a.perm = e->d_perm;
     }
     const int slots_ = resident_slots_of(e);
@@ -1629,7 +1629,7 @@ static int step_launch(ppn_engine* e, const uint8_t* actions, int32_t actions_on
     // (the throughput regime only: see K_STEP_PERSIST; not for the one-word kernels -- an IEEE-14 step is ~40 us, the trip to the
     //  position counter between two of them costs more than the workgroup launch it replaces: 37.9 vs 36.8 M at 16384)
     const bool pers = !ob && e->persistent && e->W >= 2 && n_steps == 1 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)e->batch;
-    hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, pers ? e->d_work : (int*)nullptr, slots_);
+    hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_perm, e->batch, pers ? e->d_work : (int*)nullptr, slots_, (const int*)nullptr);
     a.perm = e->d_perm;
     if (pers) { a.work_counter = e->d_work; a.n_work = e->batch; nblocks = e->resident_slots; }
   }
@@ -1807,6 +1807,7 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
     e->d_cand_actions = dalloc<u8>(e, (size_t)cap * d.alen);
     e->d_cand_obs = dalloc<double>(e, (size_t)cap * d.obslen);
     e->d_cand_ids = dalloc<int>(e, (size_t)cap);
+    e->d_cand_perm = dalloc<int>(e, (size_t)cap);
     e->cand_allocs.assign(e->allocs.begin() + mark, e->allocs.end());      // (dalloc files everything under e->allocs)
     e->allocs.resize(mark);
     if (e->mem_failed) {
@@ -1858,6 +1859,19 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
     memset(&a.ssrc, 0, sizeof a.ssrc);
   }
 #endif
+  int nb_first = n;      // workgroups of the first (or only) step launch
+#ifndef PPN_EMU
+  if (e->order_launches && n > 1024) {
+    // more candidates than resident slots: hand out the long ones first, as the stepped launch does -- a candidate inherits the
+    // loading its parent's last step left (round 6: 8192 candidates over 1024 slots in index order ended with their cascades) --
+    // and, from persistent_rounds candidates per slot on, through the persistent form of the step kernel
+    const int slots_ = e->persistent ? resident_slots_of(e, two_cap ? e->lds_small_cap : e->lds_bytes) : 0;
+    const bool pers = e->persistent && e->W >= 2 && slots_ > 0 && (long)e->persistent_rounds * slots_ <= (long)n;
+    hipLaunchKernelGGL(ppn_order_kernel, dim3(1), dim3(1024), 0, e->stream, e->st.prio, e->d_cand_perm, n, pers ? e->d_work : (int*)nullptr, slots_, (const int*)e->d_cand_ids);
+    a.perm = e->d_cand_perm;
+    if (pers) { a.work_counter = e->d_work; a.n_work = n; nb_first = slots_; }
+  }
+#endif
   if (two_cap) {
     // two-capacity stepping for the candidates as well (round 5): the pre-pass has classed every candidate's schedule; the
     // small-storage launch plays four candidates per CU, the large-storage one whatever does not fit
@@ -1865,12 +1879,12 @@ extern "C" int ppn_simulate_candidates(ppn_engine* e, const uint8_t* actions, in
     as.d.ECAP = e->ecap_small; as.d.QCAP = e->ecap_small; as.d.LUCAP = 4 * e->ecap_small;
     as.cap_class = 0;
     e->lds_override = e->lds_small_cap;
-    const int rc_s = launch<K_STEP>(e, as, n);
+    const int rc_s = as.work_counter ? launch<K_STEP_PERSIST>(e, as, nb_first) : launch<K_STEP>(e, as, n);
     e->lds_override = 0;
     if (rc_s) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
-    a.cap_class = 1;
+    a.cap_class = 1; a.work_counter = nullptr; nb_first = n;      // (the large-storage launch: plain form, the other class's workgroups return at once)
   }
-  if (launch<K_STEP>(e, a, n)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
+  if (a.work_counter ? launch<K_STEP_PERSIST>(e, a, nb_first) : launch<K_STEP>(e, a, n)) return fail(e, PPN_E_HIP, "step kernel launch failed: %s", dev_err());
   return PPN_OK;
 }
 

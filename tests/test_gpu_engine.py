@@ -294,7 +294,9 @@ def test_gpu_device_reward_matches_restatement(env, steps, batch):
     ec.check_device_reward(HIP, env, steps, batch)
 
 
-@pytest.mark.parametrize('env,batch,k', [('default14_for_tests_alpha', 48, 8), ('default118', 32, 6)])
+@pytest.mark.parametrize('env,batch,k', [('default14_for_tests_alpha', 48, 8), ('default118', 32, 6),
+                                         ('default118', 192, 8),       # (1536 candidates: more than 1024, handed out by their parents' loading -- round 6)
+                                         ('default118', 640, 8)])      # (5120: four per resident slot and more -- the persistent form of the step kernel plays them)
 def test_gpu_candidate_search_equals_simulate(env, batch, k):
     ec.check_candidate_search(HIP, env, batch, k)
 
