@@ -117,10 +117,18 @@ def taint(blocks, order):
                             if c in t and b in blocks[p]['succ']:
                                 others = [s_ for s_ in blocks[p]['succ'] if s_ != b]
                                 vals = dict((p_, v_) for v_, p_ in inc)
-                                if all(o in vals for o in others):      # (triangle: the other side of the branch comes in directly)
-                                    if any(vals[o] != v for o in others):
-                                        hot = 'join of the branch on ' + c
-                                elif any(v2 != v for v2, _ in inc):
+                                # the predecessors of this block that the OTHER side of the branch can arrive through (without passing
+                                # this block): a different value on one of them makes the phi lane-dependent
+                                seen, work, reach = set(others), list(others), set()
+                                while work and len(seen) < 4000:
+                                    x = work.pop()
+                                    if x in vals:
+                                        reach.add(x)
+                                    for s_ in blocks.get(x, {}).get('succ', []):
+                                        if s_ != b and s_ not in seen:
+                                            seen.add(s_)
+                                            work.append(s_)
+                                if any(vals[r] != v for r in reach) or len(seen) >= 4000:
                                     hot = 'join of the branch on ' + c
                             for v2, p2 in inc:
                                 if p2 != p and v2 != v and len(preds[p]) == 1 and preds[p] == preds[p2] and blocks.get(preds[p][0], {}).get('cond') in t:
