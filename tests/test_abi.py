@@ -141,3 +141,73 @@ def test_kernels_ir_has_no_lane_dependent_cycle_around_a_convergent_operation():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dev', 'ir_lint_convergent.py'), '--build'], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(' 0 reported') == 6, r.stdout
+
+
+MIR_JOIN_BLOCK = """--- |
+  ; module
+...
+---
+name:            kernel_under_test
+body:             |
+  bb.0:
+    successors: %bb.1, %bb.2
+    renamable $sgpr0_sgpr1 = COPY $exec, implicit-def $exec
+    $exec = S_MOV_B64_term killed renamable $sgpr6_sgpr7
+    S_CBRANCH_EXECZ %bb.2, implicit $exec
+
+  bb.1:
+    successors: %bb.2
+    renamable $vgpr26 = V_ACCVGPR_READ_B32_e64 $agpr111, implicit $exec
+
+  bb.2:
+  HEAD
+    $exec = S_OR_B64 $exec, killed renamable $sgpr0_sgpr1, implicit-def $scc
+    renamable $vgpr30_vgpr31 = V_MOV_B64_e32 0, implicit $exec
+    S_ENDPGM 0
+...
+"""
+
+
+def test_mir_lint_reports_a_vector_copy_in_front_of_the_exec_restore(tmp_path):
+    """The shape of GPU-only incident (i) in a dozen lines of machine IR: an SGPR copy in front of the join block's S_OR_B64 is
+    scalar code and fine, an SGPR <-> VGPR-lane spill ignores EXEC and is fine, a vector copy / spill there runs under the branch's mask."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('mir_lint_exec_restore', os.path.join(root, 'tools', 'dev', 'mir_lint_exec_restore.py'))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    heads = {
+        'clean': '  renamable $sgpr78_sgpr79 = COPY killed renamable $sgpr60_sgpr61\n    $sgpr3 = SI_RESTORE_S32_FROM_VGPR $vgpr247, 49',
+        'copy': '  renamable $agpr20 = COPY killed renamable $vgpr235\n    renamable $sgpr78_sgpr79 = COPY killed renamable $sgpr60_sgpr61',
+        'spill': '  SI_SPILL_V32_SAVE killed $vgpr235, %stack.5, $sgpr32, 0, implicit $exec :: (store (s32) into %stack.5, addrspace 5)',
+        'remat': '  renamable $vgpr109 = V_MOV_B32_e32 255, implicit $exec',
+    }
+    found = {}
+    for tag, head in heads.items():
+        p = tmp_path / (tag + '.mir')
+        p.write_text(MIR_JOIN_BLOCK.replace('HEAD', head))
+        reps, n = lint.lint(str(p))
+        assert n == 1
+        found[tag] = [(r[0], r[1]) for r in reps]
+    assert found['clean'] == []
+    assert found['copy'] == [('kernel_under_test', 'bb.2')]
+    assert found['spill'] == [('kernel_under_test', 'bb.2')]
+    assert found['remat'] == [('kernel_under_test', 'bb.2')]
+
+
+def test_kernels_mir_has_no_vector_code_in_front_of_an_exec_restore():
+    """tools/dev/mir_lint_exec_restore.py over the machine IR of all seven translation units, stopped behind the last register
+    allocation (hipcc -mllvm -stop-after=amdgpu-mark-last-scratch-load, ~80 s in parallel): no vector copy / spill / rematerialisation may stand
+    in front of a join block's `$exec = S_OR_B64 $exec, ...` -- the placement that made round 2's four-word Newton reset kernel save a
+    uniform LDS base for the lanes of one branch only (incident (i)).  On the round-2 tree the lint separates the seven known builds without a
+    GPU: the three that fail on the MI355X are reported, the four that pass are clean (profiles/r06_incident_i_mir_lint_variants.txt)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dev', 'mir_lint_exec_restore.py'), '--build'], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(' 0 vector instruction(s) in front of one') == 7, r.stdout
