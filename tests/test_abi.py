@@ -200,7 +200,8 @@ def test_kernels_mir_has_no_vector_code_in_front_of_an_exec_restore():
     allocation (hipcc -mllvm -stop-after=amdgpu-mark-last-scratch-load, ~80 s in parallel): no vector copy / spill / rematerialisation may stand
     in front of a join block's `$exec = S_OR_B64 $exec, ...` -- the placement that made round 2's four-word Newton reset kernel save a
     uniform LDS base for the lanes of one branch only (incident (i)).  On the round-2 tree the lint separates the seven known builds without a
-    GPU: the three that fail on the MI355X are reported, the four that pass are clean (profiles/r06_incident_i_mir_lint_variants.txt)."""
+    GPU: the three that fail on the MI355X are reported, the four that pass are clean (profiles/r06_incident_i_mir_lint_variants.txt); so are round 3's
+    incident (ii) (20 reports) and its fix (none): profiles/r06_incident_ii_mir_lint.txt."""
     import shutil
     import subprocess
     import sys

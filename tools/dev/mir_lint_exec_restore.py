@@ -16,7 +16,7 @@ restore.  It then runs under the narrowed mask of the `then` side: lanes that sk
 
 What is reported: every block of the MIR stopped behind the last register allocation (-stop-after=amdgpu-mark-last-scratch-load: blocks
 are not merged yet) in which an EXEC-dependent vector instruction -- anything with `implicit $exec` other than the SGPR <-> VGPR-lane
-spill pseudos, and any COPY into a vector register -- stands in front of the block's `$exec = S_OR_B64 $exec, ...` (or, for an else-block, its `S_OR_SAVEEXEC_B64`).
+spill pseudos and the whole-wave-mode spills (expanded with EXEC = -1 around them: prologue by design), and any COPY into a vector register -- stands in front of the block's `$exec = S_OR_B64 $exec, ...` (or, for an else-block, its `S_OR_SAVEEXEC_B64`).
 
     python tools/dev/mir_lint_exec_restore.py file.mir [...]      # exit status 1 if anything is reported
     python tools/dev/mir_lint_exec_restore.py --build [--keep] [flags]   # emits the MIR of the seven translation units first (80 s on 8 cores;
@@ -32,7 +32,7 @@ STOP_AFTER = 'amdgpu-mark-last-scratch-load'
 BLOCK = re.compile(r'^  (bb\.\d+[\w.\-]*)')
 NAME = re.compile(r'^name:\s+(\S+)')
 RESTORE = re.compile(r'\$exec = S_OR_B64 \$exec, |= S_OR_SAVEEXEC_B64 (killed |renamable )*\$sgpr.*implicit-def \$exec')      # SI_END_CF; SI_ELSE (the else-side's mask; `S_OR_SAVEEXEC_B64 -1` is whole-wave mode around a spill, not a join)
-SCALAR_LANE_OPS = re.compile(r'= SI_SPILL_S\d+_RESTORE|SI_SPILL_S\d+_SAVE|SI_RESTORE_S32_FROM_VGPR|SI_SPILL_S32_TO_VGPR|V_READLANE_B32|V_WRITELANE_B32|V_READFIRSTLANE_B32')
+SCALAR_LANE_OPS = re.compile(r'SI_SPILL_WWM_\w+|= SI_SPILL_S\d+_RESTORE|SI_SPILL_S\d+_SAVE|SI_RESTORE_S32_FROM_VGPR|SI_SPILL_S32_TO_VGPR|V_READLANE_B32|V_WRITELANE_B32|V_READFIRSTLANE_B32')
 VECTOR_COPY = re.compile(r'^\s+(renamable |dead |undef |early-clobber )*(\$(vgpr|agpr)\d+[\w$]*|%\d+(\.\w+)?:(vgpr|agpr|av_|vreg|areg)\w*) = COPY ')
 
 
