@@ -1575,3 +1575,56 @@ def check_candidate_schedule_cache(lib_path, batch=6, k=4, rounds=6, seed=17, so
                 assert np.array_equal(a.read(f), b.read(f), equal_nan=True), (r, f)
     a.close(); b.close()
     return n_split
+
+
+def check_register_poison(lib_path, envname='default118', solver='newton', batch=256, steps=8, seed=31, max_active_buses=None, patterns=(0x0, 0x7ff7a5a5)):
+    """GPU-only incidents (i) and (ii) were kernels whose result depended on what an EARLIER kernel had left in the register file (a spill
+    saved for the lanes of one branch only, reloaded for all).  tools/ubench/register_poison.hip (build/libppn_poison.so) leaves a pattern in every VGPR,
+    AGPR and LDS byte of the chip; it is run in front of every engine call of two engines that differ in the pattern only (0 / a NaN that is also an
+    index far out of range).  A correct kernel cannot tell the patterns apart: every field must agree bit for bit.  Random node splitting and line
+    switching with the bench limits (cascades, game overs, fused restarts, schedule builds)."""
+    import ctypes
+    import json
+    import os
+    from helpers import ENVS, ROOT
+    from pypownet_amd import _lib
+    so = os.path.join(ROOT, 'build', 'libppn_poison.so')
+    if not os.path.exists(so):
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as ge
+        ge.build_guards()
+    poison = ctypes.CDLL(so).ppn_poison
+    poison.argtypes = [ctypes.c_uint]
+    poison.restype = ctypes.c_int
+    case, cfg, chronics = load_env(envname, conf={'solver': solver})
+    case.ntopo_offset_lines = case.nP + case.nL + 2 * case.nl
+    kw = {}
+    if envname == 'default118':
+        with open(os.path.join(ENVS, 'default118', 'bench_limits.json')) as f:
+            kw['thermal_limits'] = np.asarray(json.load(f)['limits_a'])
+    if max_active_buses is not None:
+        kw['max_active_buses'] = max_active_buses
+    engs = [engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw) for _ in patterns]
+    rng = np.random.default_rng(seed)
+    for e, pat in zip(engs, patterns):
+        assert poison(pat) == 0
+        e.reset()
+        e.sync()
+    fields = [f for f in _lib.FIELD_ID]
+    n_done = 0
+    for t in range(steps):
+        acts = random_actions(case, rng, batch)
+        for e, pat in zip(engs, patterns):
+            assert poison(pat) == 0
+            e.step(acts, auto_reset=True)
+            e.sync()
+        n_done += int(engs[0].read('DONE').sum())
+        ref = {f: engs[0].read(f) for f in fields}
+        for e in engs[1:]:
+            for f in fields:
+                v = e.read(f)
+                same = ((ref[f] == v) | (np.isnan(ref[f]) & np.isnan(v))) if v.dtype.kind == 'f' else (ref[f] == v)
+                assert same.all(), 'step %d: %s depends on what was left in the register file / LDS (%d cells, first %s)' % (
+                    t, f, int((~same).sum()), tuple(np.argwhere(~same)[0]))
+    return dict(done=n_done, solves=int(engs[0].read('N_SOLVES').sum()))
