@@ -1594,6 +1594,8 @@ def check_register_poison(lib_path, envname='default118', solver='newton', batch
         sys.path.insert(0, ROOT)
         import __graft_entry__ as ge
         ge.build_guards()
+    import torch
+    torch.zeros(1, device='cuda')      # (the guard library must find the HIP runtime the process already runs on: loaded cold it reports "no ROCm-capable device")
     poison = ctypes.CDLL(so).ppn_poison
     poison.argtypes = [ctypes.c_uint]
     poison.restype = ctypes.c_int
@@ -1608,7 +1610,8 @@ def check_register_poison(lib_path, envname='default118', solver='newton', batch
     engs = [engine_with_library(lib_path, case, cfg, batch, chronics=chronics, **kw) for _ in patterns]
     rng = np.random.default_rng(seed)
     for e, pat in zip(engs, patterns):
-        assert poison(pat) == 0
+        rc = poison(pat)
+        assert rc == 0, rc
         e.reset()
         e.sync()
     fields = [f for f in _lib.FIELD_ID]
@@ -1616,7 +1619,8 @@ def check_register_poison(lib_path, envname='default118', solver='newton', batch
     for t in range(steps):
         acts = random_actions(case, rng, batch)
         for e, pat in zip(engs, patterns):
-            assert poison(pat) == 0
+            rc = poison(pat)
+            assert rc == 0, rc
             e.step(acts, auto_reset=True)
             e.sync()
         n_done += int(engs[0].read('DONE').sum())
