@@ -90,15 +90,19 @@ def main(argv):
     files = build_mir([a for a in argv[1:] if a != '--keep']) if built else argv
     if not files:
         raise SystemExit(__doc__)
-    total = 0
+    total = seen = 0
     for path in files:
         reps, n_restores = lint(path)
         total += len(reps)
+        seen += n_restores
         for func, block, pn, pl, restore in reps:
             print('%s:%d: %s %s: `%s` in front of `%s`' % (os.path.basename(path), pn, func, block, pl[:150], restore[:80]))
         print('%s: %d EXEC restores looked at, %d vector instruction(s) in front of one' % (os.path.basename(path), n_restores, len(reps)))
         if built and not keep:
             os.remove(path)           # (half a gigabyte for the seven units)
+    if seen == 0:                     # (a compiler that prints its machine IR another way must not pass for a clean one)
+        print('no EXEC restore recognised in %d file(s): the lint does not understand this MIR' % len(files))
+        return 2
     return 1 if total else 0
 
 
